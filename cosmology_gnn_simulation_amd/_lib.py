@@ -1,0 +1,117 @@
+"""ctypes binding of ``libcgnn_hip.so`` (the C ABI in ``include/cgnn.h``).
+
+There is deliberately no fallback: if the shared library is missing the first
+compute call raises, telling the user how to build it.  Python never touches
+device memory itself; it passes ``tensor.data_ptr()`` and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcgnn_hip.so")
+
+MAX_HIDDEN_LAYERS = 6
+F32, BF16 = 0, 1
+PRECISIONS = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}
+
+# every symbol include/cgnn.h declares (tests check the library exports all of them)
+EXPORTS = (
+    "cgnn_version", "cgnn_arch", "cgnn_last_error", "cgnn_packed_linear_bytes", "cgnn_pack_linear",
+    "cgnn_mlp_rows", "cgnn_project_nodes", "cgnn_edge_block", "cgnn_aggregate", "cgnn_node_block",
+    "cgnn_knn_workspace_bytes", "cgnn_knn_periodic", "cgnn_knn_sorted_order", "cgnn_segment_colsum",
+    "cgnn_gather_rows", "cgnn_scatter_rows",
+)
+
+
+class Linear(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("in_dim", C.c_int32), ("out_dim", C.c_int32)]
+
+
+class Mlp(C.Structure):
+    _fields_ = [("precision", C.c_int32), ("num_hidden_layers", C.c_int32),
+                ("layer", Linear * (MAX_HIDDEN_LAYERS + 1)),
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p)]
+
+
+class CgnnError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the library (no GPU needed for this) and declare signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise CgnnError(
+            f"{LIB_PATH} not found. Build the gfx950 kernels first: "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C cosmology_gnn_simulation_amd/csrc -j8`. There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, sz, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_float
+    lib.cgnn_version.restype = C.c_int
+    lib.cgnn_arch.restype = C.c_char_p
+    lib.cgnn_last_error.restype = C.c_char_p
+    lib.cgnn_packed_linear_bytes.restype = sz
+    lib.cgnn_packed_linear_bytes.argtypes = [i32, i32, i32]
+    lib.cgnn_pack_linear.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
+    lib.cgnn_mlp_rows.argtypes = [C.POINTER(Mlp), vp, i64, i32, vp, i32, vp]
+    lib.cgnn_project_nodes.argtypes = [C.POINTER(Linear), C.POINTER(Linear), i32, vp, i64, vp, vp, vp]
+    lib.cgnn_edge_block.argtypes = [C.POINTER(Mlp), vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, vp]
+    lib.cgnn_aggregate.argtypes = [vp, vp, vp, i64, i32, i64, i32, vp, vp]
+    lib.cgnn_node_block.argtypes = [C.POINTER(Mlp), C.POINTER(Linear), C.POINTER(Linear), vp, vp, i64, vp, i32, i32, vp]
+    lib.cgnn_knn_workspace_bytes.restype = sz
+    lib.cgnn_knn_workspace_bytes.argtypes = [i64, i32]
+    lib.cgnn_knn_periodic.argtypes = [vp, i64, f32, i32, vp, i64, vp, vp, vp, sz, vp]
+    lib.cgnn_knn_sorted_order.argtypes = [vp, i64, vp, vp]
+    lib.cgnn_segment_colsum.argtypes = [vp, vp, i64, i32, i32, vp, vp]
+    lib.cgnn_gather_rows.argtypes = [vp, vp, i64, i32, vp, vp]
+    lib.cgnn_scatter_rows.argtypes = [vp, vp, i64, i32, vp, vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name not in ("cgnn_version",):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().cgnn_last_error().decode("utf-8", "replace")
+        raise CgnnError(f"{what} failed (status {rc}): {msg}")
+
+
+def require_device(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise CgnnError(f"{name} must live on a HIP device (got {t.device}); this engine has no CPU path")
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    """float32 + contiguous view of a device tensor (copy only when needed)."""
+    require_device(t, name)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def i32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    require_device(t, name)
+    if t.dtype != torch.int32:
+        t = t.to(torch.int32)
+    return t if t.is_contiguous() else t.contiguous()

@@ -1,0 +1,286 @@
+// Shared device-side building blocks for the gfx950 kernels.
+//
+// Activation layout ("act layout").  Every fused kernel keeps a tile of 32 rows
+// (edges or nodes) per wave, TRANSPOSED: the row index sits on the MFMA column
+// (lane & 31) and the feature index on the MFMA row, so that a layer's f32
+// accumulator tile is directly the B operand of the next layer's MFMA and the
+// whole MLP -> LayerNorm -> residual chain stays in registers (no LDS round trip
+// between layers).  For feature tile t (32 features) lane l = r + 32 h holds, in
+// register i of the tile (0..15),
+//        feature  f(t,h,i) = 32 t + 8 (i >> 2) + 4 h + (i & 3)      of row r.
+// This is the C/D map of v_mfma_f32_32x32x{2_f32,16_bf16}
+// (row = (i&3) + 8 (i>>2) + 4 (lane>>5), col = lane & 31).
+//
+// Weights are pre-packed (pack.hip) so that the A operand of MFMA step
+// (out tile o, k tile kt, step) is one contiguous lane-linear fragment whose k
+// order matches f(t,h,i).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "cgnn.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define CGNN_WAVE 64
+#define CGNN_ROWS_PER_WAVE 32
+#define CGNN_BLOCK 256
+#define CGNN_WAVES_PER_BLOCK (CGNN_BLOCK / CGNN_WAVE)
+
+// (hidden/32, latent/32) pairs the fused kernels are compiled for.
+#define CGNN_FOR_EACH_PAIR(X) X(1, 1) X(2, 2) X(4, 4) X(8, 8) X(4, 2) X(4, 8)
+
+namespace cgnn {
+
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+int grid_for_tiles(int64_t tiles_of_32_rows);
+
+__device__ __forceinline__ int feat_of(int t, int h, int i) { return 32 * t + 8 * (i >> 2) + 4 * h + (i & 3); }
+
+// ---------------------------------------------------------------------------
+// MFMA operands
+// ---------------------------------------------------------------------------
+template <int PREC, int T>
+struct Operand;
+
+template <int T>
+struct Operand<CGNN_F32, T> {
+    f32x16 v[T];
+    template <bool RELU>
+    __device__ __forceinline__ void from_acc(const f32x16 (&acc)[T]) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[t][i] = RELU ? fmaxf(acc[t][i], 0.f) : acc[t][i];
+    }
+};
+
+template <int T>
+struct Operand<CGNN_BF16, T> {
+    bf16x8 v[2 * T];
+    template <bool RELU>
+    __device__ __forceinline__ void from_acc(const f32x16 (&acc)[T]) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float x = acc[t][8 * s + j];
+                    v[2 * t + s][j] = (__bf16)(RELU ? fmaxf(x, 0.f) : x);
+                }
+    }
+};
+
+// out[o] += W[o-tile, :] . in   for every out tile; wp = packed weights.
+//
+// The packed layout is flat in MFMA issue order: fragment m = (o*KT + kt)*S + s lives at wp[m*64 + lane]
+// (S = 16 k-steps of 2 for f32, 2 k-steps of 16 for bf16).  The loop is fully unrolled (both operand arrays
+// must be indexed statically to stay in registers) and software-pipelined by hand: the A fragments of group
+// g+1 are fetched while group g's MFMAs issue, and a sched_barrier closes each group so that hipcc cannot
+// hoist every load of the layer to the top (which spills).
+template <int PREC>
+struct Frag;
+template <>
+struct Frag<CGNN_F32> {
+    typedef float type;
+    static constexpr int S = 16;
+    static constexpr int GS = 16;
+};
+template <>
+struct Frag<CGNN_BF16> {
+    typedef bf16x8 type;
+    static constexpr int S = 2;
+    static constexpr int GS = 8;
+};
+
+template <int KT>
+__device__ __forceinline__ f32x16 mfma_step(float a, const Operand<CGNN_F32, KT>& in, int kt, int s, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, in.v[kt][s], c, 0, 0, 0);
+}
+template <int KT>
+__device__ __forceinline__ f32x16 mfma_step(bf16x8 a, const Operand<CGNN_BF16, KT>& in, int kt, int s, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, in.v[2 * kt + s], c, 0, 0, 0);
+}
+
+// Weight sources.  Global weights are read with buffer loads (uniform descriptor + one lane-offset VGPR +
+// a scalar/immediate fragment offset) so that no per-fragment 64-bit address is ever materialised; flat
+// global pointers made hipcc hoist one address pair per fragment out of the persistent tile loop and spill.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) bf16x8* LdsWeightPtr;
+
+template <int PREC>
+struct BufW;
+template <>
+struct BufW<CGNN_F32> {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ BufW(const void* p, unsigned bytes)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000)) {}
+    __device__ __forceinline__ float fetch(int m, int lane) const {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 4, m * 256, 0));
+    }
+};
+template <>
+struct BufW<CGNN_BF16> {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ BufW(const void* p, unsigned bytes)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000)) {}
+    __device__ __forceinline__ bf16x8 fetch(int m, int lane) const {
+        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, m * 1024, 0));
+    }
+};
+struct LdsW {
+    LdsWeightPtr p;
+    __device__ __forceinline__ explicit LdsW(LdsWeightPtr q) : p(q) {}
+    __device__ __forceinline__ bf16x8 fetch(int m, int lane) const { return p[m * 64 + lane]; }
+};
+
+template <int KT, int OT, int PREC, typename WSrc>
+__device__ __forceinline__ void dense(f32x16 (&out)[OT], const Operand<PREC, KT>& in, const WSrc& wp, int lane) {
+    typedef typename Frag<PREC>::type A;
+    constexpr int S = Frag<PREC>::S;
+    constexpr int M = OT * KT * S;
+    constexpr int GS = (M < Frag<PREC>::GS) ? M : Frag<PREC>::GS;
+    constexpr int NG = M / GS;
+    static_assert(M % GS == 0, "group size must divide the MFMA count");
+    A buf[2][GS];
+#pragma unroll
+    for (int j = 0; j < GS; ++j) buf[0][j] = wp.fetch(j, lane);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int j = 0; j < GS; ++j) buf[(g + 1) & 1][j] = wp.fetch((g + 1) * GS + j, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < GS; ++j) {
+            const int m = g * GS + j;
+            const int o = m / (KT * S), kt = (m / S) % KT, s = m % S;
+            out[o] = mfma_step<KT>(buf[g & 1][j], in, kt, s, out[o]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// act-layout tile helpers (T tiles of 32 features, one row per lane pair)
+// ---------------------------------------------------------------------------
+template <int T>
+__device__ __forceinline__ void acc_fill_bias(f32x16 (&acc)[T], const float* __restrict__ b, int out_dim, int h) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f = 32 * t + 8 * g + 4 * h;
+            if (b != nullptr && f + 3 < out_dim) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(b + f);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[t][4 * g + c] = v[c];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[t][4 * g + c] = (b != nullptr && f + c < out_dim) ? b[f + c] : 0.f;
+            }
+        }
+}
+
+// Full-width (dim == 32 T, ld % 4 == 0) row tile: 16-byte loads.
+template <int T>
+__device__ __forceinline__ void load_rows_full(f32x16 (&a)[T], const float* __restrict__ rowp, int h) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + 32 * t + 8 * g + 4 * h);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[t][4 * g + c] = v[c];
+        }
+}
+
+template <int T>
+__device__ __forceinline__ void add_rows_full(f32x16 (&a)[T], const float* __restrict__ rowp, int h) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + 32 * t + 8 * g + 4 * h);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[t][4 * g + c] += v[c];
+        }
+}
+
+template <int T>
+__device__ __forceinline__ void store_rows_full(const f32x16 (&a)[T], float* __restrict__ rowp, int h) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = a[t][4 * g + c];
+            *reinterpret_cast<f32x4*>(rowp + 32 * t + 8 * g + 4 * h) = v;
+        }
+}
+
+// Ragged width (dim not a multiple of 32, or unaligned rows): scalar, zero padded.
+template <int T>
+__device__ __forceinline__ void load_rows_ragged(f32x16 (&a)[T], const float* __restrict__ rowp, int dim, int h) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int f = feat_of(t, h, i);
+            a[t][i] = f < dim ? rowp[f] : 0.f;
+        }
+}
+
+template <int T>
+__device__ __forceinline__ void store_rows_ragged(const f32x16 (&a)[T], float* __restrict__ rowp, int dim, int h) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int f = feat_of(t, h, i);
+            if (f < dim) rowp[f] = a[t][i];
+        }
+}
+
+// LayerNorm over the 32 T features of each row (eps 1e-5, biased variance; two
+// pass: the values are in registers).  A row's features live on lanes r and r+32.
+template <int T>
+__device__ __forceinline__ void layer_norm_rows(f32x16 (&a)[T], const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, int h) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += a[t][i];
+    s += __shfl_xor(s, 32);
+    const float mean = s * (1.0f / (32 * T));
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float d = a[t][i] - mean;
+            q += d * d;
+        }
+    q += __shfl_xor(q, 32);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / (32 * T)) + 1e-5f);
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f = 32 * t + 8 * g + 4 * h;
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + f);
+            const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + f);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[t][4 * g + c] = (a[t][4 * g + c] - mean) * rstd * gm[c] + bt[c];
+        }
+}
+
+}  // namespace cgnn

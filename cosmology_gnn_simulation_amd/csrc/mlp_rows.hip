@@ -1,0 +1,205 @@
+// cgnn_mlp_rows: row-wise MLP (+LayerNorm) -- the encoders (reference graph_network.py:54,57)
+// and the decoders (:158-159) -- and cgnn_project_nodes (the sender/receiver halves of the edge
+// model's first Linear, evaluated once per node instead of once per edge).
+#include <string.h>
+
+#include "mlp_device.hpp"
+
+namespace cgnn {
+
+template <int PREC, bool WLDS, int K0T, int HT, int OT>
+__global__ __launch_bounds__(CGNN_BLOCK) void mlp_rows_kernel(MlpDev m, const float* __restrict__ x, int64_t n,
+                                                              int ld_x, float* __restrict__ y, int ld_y) {
+    if (WLDS) stage_weights_to_lds(m, 0);
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    const int64_t tiles = (n + 31) / 32;
+    const int in_dim = m.in_dim[0], out_dim = m.out_dim[m.nh];
+    const bool in_full = (in_dim == 32 * K0T) && (ld_x % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const bool out_full = (out_dim == 32 * OT) && (ld_y % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+    for (int64_t tile = (int64_t)blockIdx.x * CGNN_WAVES_PER_BLOCK + wave; tile < tiles;
+         tile += (int64_t)gridDim.x * CGNN_WAVES_PER_BLOCK) {
+        const int64_t row = tile * 32 + r;
+        const int64_t rowc = row < n ? row : n - 1;
+        Operand<PREC, K0T> op0;
+        {
+            f32x16 a[K0T];
+            if (in_full)
+                load_rows_full<K0T>(a, x + rowc * ld_x, h);
+            else
+                load_rows_ragged<K0T>(a, x + rowc * ld_x, in_dim, h);
+            op0.template from_acc<false>(a);
+        }
+        Operand<PREC, HT> oph;
+        {
+            f32x16 acc[HT];
+            acc_fill_bias<HT>(acc, m.b[0], m.out_dim[0], h);
+            dense<K0T, HT>(acc, op0, WSel<PREC, WLDS>::get(m, 0), lane);
+            oph.template from_acc<true>(acc);
+        }
+        f32x16 out[OT];
+        mlp_tail<PREC, WLDS, HT, OT>(m, oph, out, lane);
+        if (m.gamma != nullptr) layer_norm_rows<OT>(out, m.gamma, m.beta, h);
+        if (row < n) {
+            if (out_full)
+                store_rows_full<OT>(out, y + row * ld_y, h);
+            else
+                store_rows_ragged<OT>(out, y + row * ld_y, out_dim, h);
+        }
+    }
+}
+
+template <int PREC, int DT, int HT>
+__global__ __launch_bounds__(CGNN_BLOCK) void project_kernel(const void* ws, const void* wd, const float* __restrict__ bd,
+                                                             int hidden, const float* __restrict__ x, int64_t n,
+                                                             float* __restrict__ ps, float* __restrict__ pd) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wave = threadIdx.x >> 6;
+    const int64_t tiles = (n + 31) / 32;
+    constexpr unsigned wbytes = DT * HT * 1024 * (PREC == CGNN_BF16 ? 2 : 4);
+    const BufW<PREC> wsrc_s(ws, wbytes), wsrc_d(wd, wbytes);
+    for (int64_t tile = (int64_t)blockIdx.x * CGNN_WAVES_PER_BLOCK + wave; tile < tiles;
+         tile += (int64_t)gridDim.x * CGNN_WAVES_PER_BLOCK) {
+        const int64_t row = tile * 32 + r;
+        const int64_t rowc = row < n ? row : n - 1;
+        Operand<PREC, DT> op;
+        {
+            f32x16 a[DT];
+            load_rows_full<DT>(a, x + rowc * (32 * DT), h);
+            op.template from_acc<false>(a);
+        }
+        if (ps != nullptr) {
+            f32x16 acc[HT];
+            acc_fill_bias<HT>(acc, nullptr, hidden, h);
+            dense<DT, HT>(acc, op, wsrc_s, lane);
+            if (row < n) store_rows_full<HT>(acc, ps + row * (32 * HT), h);
+        }
+        if (pd != nullptr) {
+            f32x16 acc[HT];
+            acc_fill_bias<HT>(acc, bd, hidden, h);
+            dense<DT, HT>(acc, op, wsrc_d, lane);
+            if (row < n) store_rows_full<HT>(acc, pd + row * (32 * HT), h);
+        }
+    }
+}
+
+template <int PREC, bool WLDS, int K0T, int HT, int OT>
+static int launch_mlp_rows(const MlpDev& m, size_t lds, const float* x, int64_t n, int ld_x, float* y, int ld_y,
+                           hipStream_t st) {
+    auto kern = mlp_rows_kernel<PREC, WLDS, K0T, HT, OT>;
+    if (WLDS && lds > 48 * 1024) {
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                           "hipFuncSetAttribute(mlp_rows)");
+        if (rc != CGNN_OK) return rc;
+    }
+    int grid = grid_for_tiles((n + 31) / 32);
+    kern<<<grid, CGNN_BLOCK, WLDS ? lds : 0, st>>>(m, x, n, ld_x, y, ld_y);
+    return check_hip(hipGetLastError(), "cgnn_mlp_rows launch");
+}
+
+template <int PREC, int K0T, int HT, int OT>
+static int dispatch_lds(const MlpDev& m, size_t lds, const float* x, int64_t n, int ld_x, float* y, int ld_y,
+                        hipStream_t st) {
+    if (PREC == CGNN_BF16 && HT <= 4 && OT <= 4 && K0T <= 4 && lds <= CGNN_LDS_WEIGHT_BUDGET && n >= 4096)
+        return launch_mlp_rows<PREC, (PREC == CGNN_BF16 && HT <= 4 && OT <= 4 && K0T <= 4), K0T, HT, OT>(
+            m, lds, x, n, ld_x, y, ld_y, st);
+    return launch_mlp_rows<PREC, false, K0T, HT, OT>(m, lds, x, n, ld_x, y, ld_y, st);
+}
+
+}  // namespace cgnn
+
+using namespace cgnn;
+
+extern "C" {
+
+int cgnn_mlp_rows(const cgnn_mlp* mlp, const float* x, int64_t n, int32_t ld_x, float* y, int32_t ld_y,
+                  void* stream) {
+    MlpDev m;
+    size_t lds = 0;
+    int rc = make_mlp_dev(mlp, &m, &lds, "cgnn_mlp_rows");
+    if (rc != CGNN_OK) return rc;
+    if (!x || !y || n < 0 || ld_x < m.in_dim[0] || ld_y < m.out_dim[m.nh]) {
+        set_error("cgnn_mlp_rows: invalid argument (n=%lld ld_x=%d in=%d ld_y=%d out=%d)", (long long)n, ld_x,
+                  m.in_dim[0], ld_y, m.out_dim[m.nh]);
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if (n == 0) return CGNN_OK;
+    const int hidden = m.out_dim[0];
+    for (int l = 1; l < m.nh; ++l)
+        if (m.in_dim[l] != hidden || m.out_dim[l] != hidden) {
+            set_error("cgnn_mlp_rows: hidden layer %d is %dx%d, expected %dx%d", l, m.out_dim[l], m.in_dim[l], hidden,
+                      hidden);
+            return CGNN_ERR_INVALID_ARG;
+        }
+    if (m.in_dim[m.nh] != hidden || hidden % 32 != 0) {
+        set_error("cgnn_mlp_rows: hidden size %d must be a multiple of 32 and match the output layer", hidden);
+        return CGNN_ERR_UNSUPPORTED;
+    }
+    const int K0T = (m.in_dim[0] + 31) / 32, HT = hidden / 32, OT = (m.out_dim[m.nh] + 31) / 32;
+    if (m.gamma && m.out_dim[m.nh] != 32 * OT) {
+        set_error("cgnn_mlp_rows: LayerNorm width %d must be a multiple of 32", m.out_dim[m.nh]);
+        return CGNN_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int prec = mlp->precision;
+#define CGNN_TRY(P, K, H, O)                                                              \
+    if (prec == P && K0T == K && HT == H && OT == O)                                       \
+        return dispatch_lds<P, K, H, O>(m, lds, x, n, ld_x, y, ld_y, st);
+    // encoders: narrow input (<= 32 features) -> latent ; decoders: latent -> <= 32 outputs
+#define CGNN_PAIR(H, D)               \
+    CGNN_TRY(CGNN_F32, 1, H, D)       \
+    CGNN_TRY(CGNN_BF16, 1, H, D)      \
+    CGNN_TRY(CGNN_F32, D, H, 1)       \
+    CGNN_TRY(CGNN_BF16, D, H, 1)
+    CGNN_FOR_EACH_PAIR(CGNN_PAIR)
+#undef CGNN_PAIR
+#undef CGNN_TRY
+    set_error("cgnn_mlp_rows: no kernel for in=%d hidden=%d out=%d (supported: input<=32 or output<=32 with "
+              "(hidden,latent) in {(32,32),(64,64),(128,128),(256,256),(128,64),(128,256)})",
+              m.in_dim[0], hidden, m.out_dim[m.nh]);
+    return CGNN_ERR_UNSUPPORTED;
+}
+
+int cgnn_project_nodes(const cgnn_linear* ws, const cgnn_linear* wd, int32_t precision, const float* x, int64_t n,
+                       float* ps, float* pd, void* stream) {
+    if (!x || n < 0 || (!ps && !pd) || (ps && (!ws || !ws->w)) || (pd && (!wd || !wd->w))) {
+        set_error("cgnn_project_nodes: invalid argument");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    const cgnn_linear* any = ps ? ws : wd;
+    const int D = any->in_dim, H = any->out_dim;
+    if ((ps && pd) && (ws->in_dim != wd->in_dim || ws->out_dim != wd->out_dim)) {
+        set_error("cgnn_project_nodes: ws and wd shapes differ");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if (D % 32 || H % 32) {
+        set_error("cgnn_project_nodes: latent %d / hidden %d must be multiples of 32", D, H);
+        return CGNN_ERR_UNSUPPORTED;
+    }
+    if (n == 0) return CGNN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int DT = D / 32, HT = H / 32;
+    const int grid = grid_for_tiles((n + 31) / 32);
+    const void* wsp = ps ? ws->w : nullptr;
+    const void* wdp = pd ? wd->w : nullptr;
+    const float* bd = pd ? wd->b : nullptr;
+#define CGNN_PAIR(Hh, Dd)                                                                                       \
+    if (HT == Hh && DT == Dd) {                                                                                  \
+        if (precision == CGNN_F32)                                                                               \
+            project_kernel<CGNN_F32, Dd, Hh><<<grid, CGNN_BLOCK, 0, st>>>(wsp, wdp, bd, H, x, n, ps, pd);         \
+        else if (precision == CGNN_BF16)                                                                         \
+            project_kernel<CGNN_BF16, Dd, Hh><<<grid, CGNN_BLOCK, 0, st>>>(wsp, wdp, bd, H, x, n, ps, pd);        \
+        else {                                                                                                   \
+            set_error("cgnn_project_nodes: unknown precision %d", precision);                                    \
+            return CGNN_ERR_INVALID_ARG;                                                                         \
+        }                                                                                                        \
+        return check_hip(hipGetLastError(), "cgnn_project_nodes launch");                                        \
+    }
+    CGNN_FOR_EACH_PAIR(CGNN_PAIR)
+#undef CGNN_PAIR
+    set_error("cgnn_project_nodes: no kernel for latent=%d hidden=%d", D, H);
+    return CGNN_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

@@ -1,0 +1,342 @@
+// Library queries, error plumbing, weight packing and the bandwidth-bound
+// utility kernels (aggregation, row gather/scatter, segmented column sum).
+#include <stdarg.h>
+#include <string.h>
+
+#include "cgnn_common.hpp"
+
+namespace cgnn {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return CGNN_OK;
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return CGNN_ERR_HIP;
+}
+
+static int g_num_cu = 0;
+
+static int num_cus() {
+    if (g_num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+            g_num_cu = p.multiProcessorCount;
+        if (g_num_cu <= 0) g_num_cu = 256;
+    }
+    return g_num_cu;
+}
+
+// One wave owns one 32-row tile at a time; blocks are persistent (grid-stride).
+int grid_for_tiles(int64_t tiles) {
+    int64_t blocks = (tiles + CGNN_WAVES_PER_BLOCK - 1) / CGNN_WAVES_PER_BLOCK;
+    const int64_t cap = (int64_t)num_cus() * 2;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+int num_compute_units() { return num_cus(); }
+
+// ------------------------------------------------------------------ packing
+__global__ void pack_f32_kernel(const float* __restrict__ w, int out_dim, int ld, int col0, int ncols, int KT,
+                                int64_t total, float* __restrict__ wp) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int l = (int)(idx & 63);
+    const int i = (int)((idx >> 6) & 15);
+    const int64_t okt = idx >> 10;
+    const int kt = (int)(okt % KT);
+    const int o = (int)(okt / KT);
+    const int row = 32 * o + (l & 31);
+    const int k = 32 * kt + 8 * (i >> 2) + 4 * (l >> 5) + (i & 3);
+    wp[idx] = (row < out_dim && k < ncols) ? w[(int64_t)row * ld + col0 + k] : 0.f;
+}
+
+__global__ void pack_bf16_kernel(const float* __restrict__ w, int out_dim, int ld, int col0, int ncols, int KT,
+                                 int64_t total, __bf16* __restrict__ wp) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int j = (int)(idx & 7);
+    const int l = (int)((idx >> 3) & 63);
+    const int s = (int)((idx >> 9) & 1);
+    const int64_t okt = idx >> 10;
+    const int kt = (int)(okt % KT);
+    const int o = (int)(okt / KT);
+    const int row = 32 * o + (l & 31);
+    const int k = 32 * kt + 16 * s + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+    const float v = (row < out_dim && k < ncols) ? w[(int64_t)row * ld + col0 + k] : 0.f;
+    wp[idx] = (__bf16)v;
+}
+
+// ------------------------------------------------------------------ aggregation
+// Fixed in-degree, receiver-sorted: one (row, 16-byte chunk) per thread; the k
+// neighbour rows are read with 16 B per lane, a row's chunks on adjacent lanes.
+__global__ void aggregate_fixedk_kernel(const float* __restrict__ table, const int32_t* __restrict__ gather,
+                                        int k, int64_t num_nodes, int chunks, float* __restrict__ out) {
+    const int64_t total = num_nodes * chunks;
+    for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
+         gid += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = gid / chunks;
+        const int c = (int)(gid - row * chunks);
+        const int64_t e0 = row * k;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int j = 0; j < k; ++j) {
+            const int64_t idx = gather ? (int64_t)gather[e0 + j] : (e0 + j);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(table + (idx * chunks + c) * 4);
+            acc += v;
+        }
+        *reinterpret_cast<f32x4*>(out + gid * 4) = acc;
+    }
+}
+
+// General edge list: each group of `chunks` lanes walks a contiguous run of edges
+// and flushes one atomic row per destination change.
+__global__ void aggregate_atomic_kernel(const float* __restrict__ table, const int32_t* __restrict__ gather,
+                                        const int32_t* __restrict__ dst, int64_t num_edges, int chunks,
+                                        int edges_per_group, float* __restrict__ out) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t group = gid / chunks;
+    const int c = (int)(gid - group * chunks);
+    const int64_t e0 = group * edges_per_group;
+    if (e0 >= num_edges) return;
+    const int64_t e1 = (e0 + edges_per_group < num_edges) ? e0 + edges_per_group : num_edges;
+    int cur = dst[e0];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t e = e0; e < e1; ++e) {
+        const int d = dst[e];
+        if (d != cur) {
+            float* o = out + ((int64_t)cur * chunks + c) * 4;
+            atomicAdd(o + 0, acc[0]);
+            atomicAdd(o + 1, acc[1]);
+            atomicAdd(o + 2, acc[2]);
+            atomicAdd(o + 3, acc[3]);
+            acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            cur = d;
+        }
+        const int64_t idx = gather ? (int64_t)gather[e] : e;
+        acc += *reinterpret_cast<const f32x4*>(table + (idx * chunks + c) * 4);
+    }
+    float* o = out + ((int64_t)cur * chunks + c) * 4;
+    atomicAdd(o + 0, acc[0]);
+    atomicAdd(o + 1, acc[1]);
+    atomicAdd(o + 2, acc[2]);
+    atomicAdd(o + 3, acc[3]);
+}
+
+// ------------------------------------------------------------------ rows
+__global__ void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ idx, int64_t n_idx,
+                                   int chunks, float* __restrict__ out) {
+    const int64_t total = n_idx * chunks;
+    for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
+         gid += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = gid / chunks;
+        const int c = (int)(gid - row * chunks);
+        *reinterpret_cast<f32x4*>(out + gid * 4) =
+            *reinterpret_cast<const f32x4*>(table + ((int64_t)idx[row] * chunks + c) * 4);
+    }
+}
+
+__global__ void scatter_rows_kernel(const float* __restrict__ rows, const int32_t* __restrict__ idx, int64_t n_idx,
+                                    int chunks, float* __restrict__ table) {
+    const int64_t total = n_idx * chunks;
+    for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
+         gid += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = gid / chunks;
+        const int c = (int)(gid - row * chunks);
+        *reinterpret_cast<f32x4*>(table + ((int64_t)idx[row] * chunks + c) * 4) =
+            *reinterpret_cast<const f32x4*>(rows + gid * 4);
+    }
+}
+
+// Scalar-width variants (width not a multiple of 4).
+__global__ void gather_rows_scalar_kernel(const float* __restrict__ table, const int32_t* __restrict__ idx,
+                                          int64_t n_idx, int width, float* __restrict__ out) {
+    const int64_t total = n_idx * width;
+    for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
+         gid += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = gid / width;
+        out[gid] = table[(int64_t)idx[row] * width + (gid - row * width)];
+    }
+}
+
+__global__ void scatter_rows_scalar_kernel(const float* __restrict__ rows, const int32_t* __restrict__ idx,
+                                           int64_t n_idx, int width, float* __restrict__ table) {
+    const int64_t total = n_idx * width;
+    for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
+         gid += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = gid / width;
+        table[(int64_t)idx[row] * width + (gid - row * width)] = rows[gid];
+    }
+}
+
+// ------------------------------------------------------------------ momentum
+// Each block owns a contiguous run of rows.  Runs inside one graph are reduced in
+// double precision in LDS and flushed with one atomic per column.
+#define CGNN_COLSUM_ROWS 2048
+__global__ void segment_colsum_kernel(const float* __restrict__ acc, const int32_t* __restrict__ batch, int64_t n,
+                                      int width, double* __restrict__ sums) {
+    __shared__ double red[CGNN_BLOCK];
+    const int64_t r0 = (int64_t)blockIdx.x * CGNN_COLSUM_ROWS;
+    const int64_t r1 = (r0 + CGNN_COLSUM_ROWS < n) ? r0 + CGNN_COLSUM_ROWS : n;
+    const int g0 = batch ? batch[r0] : 0;
+    const int g1 = batch ? batch[r1 - 1] : 0;
+    if (g0 == g1) {
+        for (int c = 0; c < width; ++c) {
+            double s = 0.0;
+            for (int64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) s += (double)acc[r * width + c];
+            red[threadIdx.x] = s;
+            __syncthreads();
+            for (int off = CGNN_BLOCK / 2; off > 0; off >>= 1) {
+                if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) atomicAdd(&sums[(int64_t)g0 * width + c], red[0]);
+            __syncthreads();
+        }
+    } else {
+        for (int64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+            const int g = batch[r];
+            for (int c = 0; c < width; ++c) atomicAdd(&sums[(int64_t)g * width + c], (double)acc[r * width + c]);
+        }
+    }
+}
+
+static inline int blocks_for(int64_t total, int cap_mult = 16) {
+    int64_t b = (total + CGNN_BLOCK - 1) / CGNN_BLOCK;
+    const int64_t cap = (int64_t)num_cus() * cap_mult;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace cgnn
+
+using namespace cgnn;
+
+extern "C" {
+
+int cgnn_version(void) { return CGNN_VERSION; }
+const char* cgnn_arch(void) { return "gfx950"; }
+const char* cgnn_last_error(void) { return g_err; }
+
+size_t cgnn_packed_linear_bytes(int32_t out_dim, int32_t ncols, int32_t precision) {
+    if (out_dim <= 0 || ncols <= 0) return 0;
+    const size_t ot = (size_t)(out_dim + 31) / 32, kt = (size_t)(ncols + 31) / 32;
+    return ot * kt * 1024 * (precision == CGNN_BF16 ? 2 : 4);
+}
+
+int cgnn_pack_linear(const float* w, int32_t out_dim, int32_t ld, int32_t col0, int32_t ncols, int32_t precision,
+                     void* packed, void* stream) {
+    if (!w || !packed || out_dim <= 0 || ncols <= 0 || ld < col0 + ncols || col0 < 0) {
+        set_error("cgnn_pack_linear: invalid argument");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    const int OT = (out_dim + 31) / 32, KT = (ncols + 31) / 32;
+    const int64_t total = (int64_t)OT * KT * 1024;
+    const int blocks = (int)((total + CGNN_BLOCK - 1) / CGNN_BLOCK);
+    hipStream_t st = (hipStream_t)stream;
+    if (precision == CGNN_F32)
+        pack_f32_kernel<<<blocks, CGNN_BLOCK, 0, st>>>(w, out_dim, ld, col0, ncols, KT, total, (float*)packed);
+    else if (precision == CGNN_BF16)
+        pack_bf16_kernel<<<blocks, CGNN_BLOCK, 0, st>>>(w, out_dim, ld, col0, ncols, KT, total, (__bf16*)packed);
+    else {
+        set_error("cgnn_pack_linear: unknown precision %d", precision);
+        return CGNN_ERR_INVALID_ARG;
+    }
+    return check_hip(hipGetLastError(), "cgnn_pack_linear launch");
+}
+
+int cgnn_aggregate(const float* table, const int32_t* gather, const int32_t* dst, int64_t num_edges,
+                   int32_t fixed_k, int64_t num_nodes, int32_t width, float* out, void* stream) {
+    if (!table || !out || num_edges < 0 || num_nodes < 0 || width <= 0 || fixed_k < 0) {
+        set_error("cgnn_aggregate: invalid argument");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if (width % 4 != 0) {
+        set_error("cgnn_aggregate: width %d is not a multiple of 4", width);
+        return CGNN_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int chunks = width / 4;
+    if (num_nodes == 0) return CGNN_OK;
+    if (fixed_k > 0) {
+        if (num_edges != num_nodes * fixed_k) {
+            set_error("cgnn_aggregate: fixed_k=%d needs num_edges == num_nodes*k (%lld vs %lld)", fixed_k,
+                      (long long)num_edges, (long long)(num_nodes * fixed_k));
+            return CGNN_ERR_INVALID_ARG;
+        }
+        aggregate_fixedk_kernel<<<blocks_for(num_nodes * chunks, 64), CGNN_BLOCK, 0, st>>>(table, gather, fixed_k,
+                                                                                        num_nodes, chunks, out);
+        return check_hip(hipGetLastError(), "cgnn_aggregate(fixed_k) launch");
+    }
+    if (!dst && num_edges > 0) {
+        set_error("cgnn_aggregate: dst is required when fixed_k == 0");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    int rc = check_hip(hipMemsetAsync(out, 0, (size_t)num_nodes * width * sizeof(float), st), "cgnn_aggregate memset");
+    if (rc != CGNN_OK || num_edges == 0) return rc;
+    const int epg = 16;
+    const int64_t groups = (num_edges + epg - 1) / epg;
+    const int64_t threads = groups * chunks;
+    const int64_t blocks = (threads + CGNN_BLOCK - 1) / CGNN_BLOCK;
+    aggregate_atomic_kernel<<<(unsigned)blocks, CGNN_BLOCK, 0, st>>>(table, gather, dst, num_edges, chunks, epg, out);
+    return check_hip(hipGetLastError(), "cgnn_aggregate(atomic) launch");
+}
+
+int cgnn_gather_rows(const float* table, const int32_t* idx, int64_t n_idx, int32_t width, float* out, void* stream) {
+    if (!table || !idx || !out || n_idx < 0 || width <= 0) {
+        set_error("cgnn_gather_rows: invalid argument");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if (n_idx == 0) return CGNN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (width % 4 == 0)
+        gather_rows_kernel<<<blocks_for(n_idx * (width / 4), 32), CGNN_BLOCK, 0, st>>>(table, idx, n_idx, width / 4, out);
+    else
+        gather_rows_scalar_kernel<<<blocks_for(n_idx * width, 32), CGNN_BLOCK, 0, st>>>(table, idx, n_idx, width, out);
+    return check_hip(hipGetLastError(), "cgnn_gather_rows launch");
+}
+
+int cgnn_scatter_rows(const float* rows, const int32_t* idx, int64_t n_idx, int32_t width, float* table,
+                      void* stream) {
+    if (!table || !idx || !rows || n_idx < 0 || width <= 0) {
+        set_error("cgnn_scatter_rows: invalid argument");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if (n_idx == 0) return CGNN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (width % 4 == 0)
+        scatter_rows_kernel<<<blocks_for(n_idx * (width / 4), 32), CGNN_BLOCK, 0, st>>>(rows, idx, n_idx, width / 4,
+                                                                                   table);
+    else
+        scatter_rows_scalar_kernel<<<blocks_for(n_idx * width, 32), CGNN_BLOCK, 0, st>>>(rows, idx, n_idx, width,
+                                                                                     table);
+    return check_hip(hipGetLastError(), "cgnn_scatter_rows launch");
+}
+
+int cgnn_segment_colsum(const float* acc, const int32_t* batch, int64_t n, int32_t width, int32_t num_graphs,
+                        double* sums, void* stream) {
+    if (!acc || !sums || n < 0 || width <= 0 || num_graphs <= 0) {
+        set_error("cgnn_segment_colsum: invalid argument");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int rc = check_hip(hipMemsetAsync(sums, 0, (size_t)num_graphs * width * sizeof(double), st),
+                       "cgnn_segment_colsum memset");
+    if (rc != CGNN_OK || n == 0) return rc;
+    const int64_t blocks = (n + CGNN_COLSUM_ROWS - 1) / CGNN_COLSUM_ROWS;
+    segment_colsum_kernel<<<(unsigned)blocks, CGNN_BLOCK, 0, st>>>(acc, batch, n, width, sums);
+    return check_hip(hipGetLastError(), "cgnn_segment_colsum launch");
+}
+
+}  // extern "C"

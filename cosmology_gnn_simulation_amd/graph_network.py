@@ -1,0 +1,383 @@
+"""Drop-in for the reference's ``graph_network`` module, running on gfx950 HIP kernels.
+
+Same public names, constructor signatures, ``state_dict`` keys and return types as
+reference graph_network.py (``build_mlp`` :15, ``GraphIndependent`` :39,
+``InteractionNetwork`` :67, ``EncodeProcessDecode`` :108), so ``train.py`` /
+``one_step_test.py`` style drivers only change their import.  The torch modules
+here are parameter containers; every forward runs the fused kernels of
+``libcgnn_hip.so`` (``ops.py``).  Tensors must be on a HIP device: there is no CPU
+path and no silent fallback.
+
+Engine knobs (attributes, not constructor arguments, so the reference signature
+is untouched):
+
+``message_source``  ``"x_j"`` (default) reproduces the reference exactly: it never
+    overrides ``MessagePassing.message``, so PyG aggregates the *sender node
+    latents* and the updated edge latents never reach the nodes.
+    ``"edge"`` aggregates the updated edge latents (the Interaction Network the
+    reference's docstrings describe).
+``edge_precision`` / ``node_precision``  ``"fp32"`` (exact f32 MFMA, default) or
+    ``"bf16"`` (bf16 MFMA operands, f32 accumulation, f32 LayerNorm/residual).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import CgnnError, require_device
+from .graph import Data
+
+__all__ = ["build_mlp", "GraphIndependent", "InteractionNetwork", "EncodeProcessDecode"]
+
+
+# ----------------------------------------------------------------------------
+# module structure (parameter containers)
+# ----------------------------------------------------------------------------
+
+def build_mlp(hidden_size: int, num_hidden_layers: int, output_size: int) -> nn.Module:
+    """``num_hidden_layers`` x (Linear, ReLU) then Linear(output_size); the first
+    Linear is lazy so its fan-in is taken from the first input
+    (reference graph_network.py:15-32; Linears sit at even Sequential indices)."""
+    mods: List[nn.Module] = [nn.LazyLinear(hidden_size), nn.ReLU(inplace=True)]
+    for _ in range(num_hidden_layers - 1):
+        mods += [nn.Linear(hidden_size, hidden_size), nn.ReLU(inplace=True)]
+    if num_hidden_layers < 1:
+        mods = []
+    mods.append(nn.Linear(hidden_size, output_size))
+    return nn.Sequential(*mods)
+
+
+def _split_mlp(module: nn.Module) -> Tuple[List[nn.Module], Optional[nn.LayerNorm]]:
+    """``Sequential(mlp, LayerNorm)`` or a bare ``build_mlp`` -> (linears, layer_norm)."""
+    ln = None
+    body = module
+    if isinstance(module, nn.Sequential) and len(module) == 2 and isinstance(module[1], nn.LayerNorm):
+        body, ln = module[0], module[1]
+    if not isinstance(body, nn.Sequential):
+        raise TypeError("the fused kernels need models built by build_mlp (optionally followed by LayerNorm); "
+                        f"got {type(body).__name__}")
+    linears = []
+    for i, m in enumerate(body):
+        if i % 2 == 0:
+            if not isinstance(m, (nn.Linear, nn.LazyLinear)):
+                raise TypeError(f"expected Linear at position {i} of the MLP, got {type(m).__name__}")
+            linears.append(m)
+        elif not isinstance(m, nn.ReLU):
+            raise TypeError(f"expected ReLU at position {i} of the MLP, got {type(m).__name__}")
+    if len(linears) < 2 or len(body) != 2 * len(linears) - 1:
+        raise TypeError("the fused kernels need at least one hidden layer and a Linear output layer")
+    if ln is not None and (not ln.elementwise_affine or abs(ln.eps - 1e-5) > 0 or len(ln.normalized_shape) != 1):
+        raise TypeError("LayerNorm must be 1-D, affine, eps=1e-5 (torch defaults, as in the reference)")
+    return linears, ln
+
+
+def _materialize(linear: nn.Module, in_features: int) -> None:
+    """Give a LazyLinear its shape exactly as its first forward would (same RNG draw)."""
+    if isinstance(linear, nn.LazyLinear) and linear.has_uninitialized_params():
+        dev = linear.bias.device if linear.bias is not None else None
+        with torch.no_grad():
+            linear(torch.zeros((0, in_features), device=dev))
+
+
+def _needs_grad(module: nn.Module) -> bool:
+    return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+
+
+_TRAINING_MSG = ("the fused HIP forward has no backward kernels yet (SURVEY.md section 8f-1): call it under "
+                 "torch.no_grad() / model.requires_grad_(False)")
+
+
+def _params_key(module: nn.Module, *extra) -> tuple:
+    return tuple((p.data_ptr(), p._version) for p in module.parameters()) + tuple(extra)
+
+
+def _wb(lin: nn.Module):
+    return lin.weight, lin.bias
+
+
+def _pack_mlp(module: nn.Module, precision, first_layer_cols=None) -> ops.PackedMLP:
+    linears, ln = _split_mlp(module)
+    return ops.PackedMLP([_wb(l) for l in linears], None if ln is None else (ln.weight, ln.bias), precision,
+                         first_layer_cols)
+
+
+# ----------------------------------------------------------------------------
+# graph arrays the kernels want (int32, fixed in-degree detection)
+# ----------------------------------------------------------------------------
+
+def _graph_arrays(data, num_nodes: int):
+    """-> (src int32 [E], dst int32 [E], fixed_k).  ``fixed_k`` > 0 when the edge
+    list is receiver-sorted with exactly k edges per receiver, which is what
+    ``data_utils.preprocess`` emits.  Cached on the data object."""
+    ei = data.edge_index
+    require_device(ei, "edge_index")
+    key = (ei.data_ptr(), ei._version, tuple(ei.shape))
+    cached = getattr(data, "_cgnn_graph", None)
+    if cached is not None and cached[0] == key:
+        return cached[1:]
+    src = ei[0].to(torch.int32).contiguous()
+    dst = ei[1].to(torch.int32).contiguous()
+    ne = ei.shape[1]
+    fixed_k = 0
+    hint = getattr(data, "_cgnn_fixed_k", None)
+    if hint is not None and num_nodes * int(hint) == ne:
+        fixed_k = int(hint)
+    elif num_nodes > 0 and ne > 0 and ne % num_nodes == 0:
+        k = ne // num_nodes
+        want = torch.arange(num_nodes, device=ei.device, dtype=torch.int32).repeat_interleave(k)
+        if bool(torch.equal(dst, want)):
+            fixed_k = k
+    try:
+        data._cgnn_graph = (key, src, dst, fixed_k)
+    except Exception:  # foreign Data types may refuse private attributes
+        pass
+    return src, dst, fixed_k
+
+
+# ----------------------------------------------------------------------------
+# modules
+# ----------------------------------------------------------------------------
+
+class GraphIndependent(nn.Module):
+    """Independent node / edge encoders (reference graph_network.py:39-64)."""
+
+    def __init__(self, node_model: nn.Module, edge_model: nn.Module):
+        super().__init__()
+        self.node_model = node_model
+        self.edge_model = edge_model
+        self.node_precision = "fp32"
+        self.edge_precision = "fp32"
+        self._packed = None
+
+    def _pack(self, node_in: int, edge_in: Optional[int]):
+        _materialize(_split_mlp(self.node_model)[0][0], node_in)
+        if edge_in is not None:
+            _materialize(_split_mlp(self.edge_model)[0][0], edge_in)
+        key = _params_key(self, self.node_precision, self.edge_precision, edge_in is None)
+        if self._packed is None or self._packed[0] != key:
+            pn = _pack_mlp(self.node_model, self.node_precision)
+            pe = _pack_mlp(self.edge_model, self.edge_precision) if edge_in is not None else None
+            self._packed = (key, pn, pe)
+        return self._packed[1], self._packed[2]
+
+    def forward(self, data) -> Data:
+        if _needs_grad(self):
+            raise NotImplementedError(_TRAINING_MSG)
+        x = data.x
+        require_device(x, "data.x")
+        ea = getattr(data, "edge_attr", None)
+        with torch.no_grad():
+            pn, pe = self._pack(x.shape[1], None if ea is None else ea.shape[1])
+            new_x = ops.mlp_rows(pn, x)
+            new_e = ops.mlp_rows(pe, ea) if ea is not None else None
+        out = Data(x=new_x, edge_index=data.edge_index, edge_attr=new_e)
+        if hasattr(data, "globals"):
+            out.globals = data.globals
+        for hint in ("_cgnn_fixed_k", "_cgnn_graph"):
+            if hasattr(data, hint):
+                setattr(out, hint, getattr(data, hint))
+        return out
+
+
+class _PackedProcessor:
+    """Packed weights of one InteractionNetwork round."""
+
+    def __init__(self, net: "InteractionNetwork", latent: int, edge_precision, node_precision):
+        e_lin, e_ln = _split_mlp(net.edge_model)
+        n_lin, n_ln = _split_mlp(net.node_model)
+        if e_ln is None or n_ln is None:
+            raise TypeError("InteractionNetwork models must end in LayerNorm (build_mlp_with_layer_norm)")
+        D = latent
+        _materialize(e_lin[0], 3 * D)
+        _materialize(n_lin[0], 2 * D)
+        w1e, b1e = _wb(e_lin[0])
+        w1n, b1n = _wb(n_lin[0])
+        if w1e.shape[1] != 3 * D or w1n.shape[1] != 2 * D:
+            raise CgnnError(f"first-layer fan-in {w1e.shape[1]}/{w1n.shape[1]} does not match latent size {D}")
+        # cat([x[src], x[dest], edge_attr]) -> [Ws | Wd | We]      (reference graph_network.py:89)
+        self.ws = ops.PackedLinear(w1e, None, edge_precision, 0, D)
+        self.wd = ops.PackedLinear(w1e, b1e, edge_precision, D, D)
+        self.edge = _pack_mlp(net.edge_model, edge_precision, first_layer_cols=(2 * D, D))
+        # cat([x, aggregated]) -> [Wx | Wa]                         (reference graph_network.py:94)
+        self.wx = ops.PackedLinear(w1n, b1n, node_precision, 0, D)
+        self.wa = ops.PackedLinear(w1n, None, node_precision, D, D)
+        self.node = _pack_mlp(net.node_model, node_precision, first_layer_cols=(0, D))
+
+
+def _run_round(p: _PackedProcessor, x: torch.Tensor, e: torch.Tensor, src, dst, fixed_k: int, message_source: str,
+               residual: bool, x_out=None, e_out=None, scratch=None):
+    """One message-passing round.  Returns (x_new, e_new)."""
+    n = x.shape[0]
+    ps = pd = agg = e_upd = None
+    if scratch is not None:
+        ps, pd, agg, e_upd = scratch
+    ps, pd = ops.project_nodes(p.ws, p.wd, x, ps, pd)
+    if message_source == "edge" and e_upd is None:
+        e_upd = torch.empty_like(e)
+    e_new = ops.edge_block(p.edge, ps, pd, src, dst, e, e_out, e_upd if message_source == "edge" else None, residual)
+    if message_source == "x_j":
+        agg = ops.aggregate(x, src, dst, n, fixed_k, src.numel(), agg)
+    elif message_source == "edge":
+        agg = ops.aggregate(e_upd, None, dst, n, fixed_k, src.numel(), agg)
+    else:
+        raise ValueError(f"message_source must be 'x_j' or 'edge', got {message_source!r}")
+    x_new = ops.node_block(p.node, p.wx, p.wa, x, agg, x_out, residual)
+    return x_new, e_new
+
+
+class InteractionNetwork(nn.Module):
+    """One round of message passing without residuals (reference
+    graph_network.py:67-101): edge update from (sender, receiver, edge), sum
+    aggregation at the receivers, node update from (node, aggregate)."""
+
+    def __init__(self, node_model: nn.Module, edge_model: nn.Module, aggr: str = "add"):
+        super().__init__()
+        if aggr != "add":
+            raise NotImplementedError("only aggr='add' is built (the reference never uses another)")
+        self.aggr = aggr
+        self.node_model = node_model
+        self.edge_model = edge_model
+        self.message_source = "x_j"
+        self.node_precision = "fp32"
+        self.edge_precision = "fp32"
+        self._packed = None
+
+    def _pack(self, latent: int) -> _PackedProcessor:
+        key = None
+        lazy = any(isinstance(m, nn.LazyLinear) and m.has_uninitialized_params() for m in self.modules())
+        if not lazy:
+            key = _params_key(self, self.node_precision, self.edge_precision, latent)
+            if self._packed is not None and self._packed[0] == key:
+                return self._packed[1]
+        packed = _PackedProcessor(self, latent, self.edge_precision, self.node_precision)
+        self._packed = (_params_key(self, self.node_precision, self.edge_precision, latent), packed)
+        return packed
+
+    def forward(self, data) -> Data:
+        x, edge_attr = data.x, getattr(data, "edge_attr", None)
+        if edge_attr is None:
+            raise ValueError("edge_attr must not be None in InteractionNetwork")
+        if _needs_grad(self):
+            raise NotImplementedError(_TRAINING_MSG)
+        require_device(x, "data.x")
+        with torch.no_grad():
+            src, dst, fixed_k = _graph_arrays(data, x.shape[0])
+            p = self._pack(x.shape[1])
+            xf, ef = x.float().contiguous(), edge_attr.float().contiguous()
+            new_x, new_e = _run_round(p, xf, ef, src, dst, fixed_k, self.message_source, residual=False)
+        out = Data(x=new_x, edge_index=data.edge_index, edge_attr=new_e)
+        if hasattr(data, "globals"):
+            out.globals = data.globals
+        for hint in ("_cgnn_fixed_k", "_cgnn_graph"):
+            if hasattr(data, hint):
+                setattr(out, hint, getattr(data, hint))
+        return out
+
+
+class EncodeProcessDecode(nn.Module):
+    """Encoder, ``num_message_passing_steps`` residual InteractionNetwork rounds, and
+    the acceleration / temperature-rate decoders (reference graph_network.py:108-183).
+    ``forward`` returns ``{'acceleration': [N, output_size], 'temp_rate': [N, 1]}``."""
+
+    def __init__(self, latent_size: int, mlp_hidden_size: int, mlp_num_hidden_layers: int,
+                 num_message_passing_steps: int, output_size: int):
+        super().__init__()
+        self._latent_size = latent_size
+        self._mlp_hidden_size = mlp_hidden_size
+        self._mlp_num_hidden_layers = mlp_num_hidden_layers
+        self._num_message_passing_steps = num_message_passing_steps
+        self._output_size = output_size
+
+        def mlp_ln() -> nn.Module:
+            return nn.Sequential(build_mlp(mlp_hidden_size, mlp_num_hidden_layers, latent_size),
+                                 nn.LayerNorm(latent_size))
+
+        self.encoder = GraphIndependent(node_model=mlp_ln(), edge_model=mlp_ln())
+        self.processor = nn.ModuleList(
+            [InteractionNetwork(edge_model=mlp_ln(), node_model=mlp_ln()) for _ in range(num_message_passing_steps)])
+        self.decoder_acc = build_mlp(mlp_hidden_size, mlp_num_hidden_layers, output_size)
+        self.decoder_temp_rate = build_mlp(mlp_hidden_size, mlp_num_hidden_layers, 1)
+
+        self.message_source = "x_j"
+        self.node_precision = "fp32"
+        self.edge_precision = "fp32"
+        self._packed = None
+
+    # -- packing ---------------------------------------------------------------
+    def _materialize_all(self, node_in: int, edge_in: int) -> None:
+        """Shape every LazyLinear in the order the reference's first forward would
+        (encoder node, encoder edge, per round edge then node, decoders), so a
+        seeded random initialisation matches the reference's."""
+        D = self._latent_size
+        _materialize(_split_mlp(self.encoder.node_model)[0][0], node_in)
+        _materialize(_split_mlp(self.encoder.edge_model)[0][0], edge_in)
+        for net in self.processor:
+            _materialize(_split_mlp(net.edge_model)[0][0], 3 * D)
+            _materialize(_split_mlp(net.node_model)[0][0], 2 * D)
+        _materialize(_split_mlp(self.decoder_acc)[0][0], D)
+        _materialize(_split_mlp(self.decoder_temp_rate)[0][0], D)
+
+    def _pack(self, node_in: int, edge_in: int):
+        self._materialize_all(node_in, edge_in)
+        key = _params_key(self, self.node_precision, self.edge_precision)
+        if self._packed is not None and self._packed[0] == key:
+            return self._packed[1]
+        D = self._latent_size
+        packed = dict(
+            enc_node=_pack_mlp(self.encoder.node_model, self.node_precision),
+            enc_edge=_pack_mlp(self.encoder.edge_model, self.edge_precision),
+            rounds=[_PackedProcessor(net, D, self.edge_precision, self.node_precision) for net in self.processor],
+            dec_acc=_pack_mlp(self.decoder_acc, self.node_precision),
+            dec_tr=_pack_mlp(self.decoder_temp_rate, self.node_precision),
+        )
+        self._packed = (key, packed)
+        return packed
+
+    # -- forward ---------------------------------------------------------------
+    def forward(self, input_graph) -> dict:
+        out = self._forward(input_graph, want_latents=False)
+        return {"acceleration": out["acceleration"], "temp_rate": out["temp_rate"]}
+
+    def forward_with_latents(self, input_graph) -> dict:
+        """Same as :meth:`forward` plus ``x_latent`` / ``edge_latent`` after the last round."""
+        return self._forward(input_graph, want_latents=True)
+
+    def _forward(self, g, want_latents: bool) -> dict:
+        if _needs_grad(self):
+            raise NotImplementedError(_TRAINING_MSG)
+        x = g.x
+        require_device(x, "input_graph.x")
+        edge_attr = getattr(g, "edge_attr", None)
+        if edge_attr is None:
+            raise ValueError("edge_attr must not be None in InteractionNetwork")
+        with torch.no_grad():
+            glob = getattr(g, "globals", None)
+            if glob is not None:  # reference graph_network.py:168-173 (never set by its own drivers)
+                x = torch.cat([x, glob.unsqueeze(0).expand(x.shape[0], -1)], dim=-1)
+            x = x.float().contiguous()
+            edge_attr = edge_attr.float().contiguous()
+            n = x.shape[0]
+            src, dst, fixed_k = _graph_arrays(g, n)
+            P = self._pack(x.shape[1], edge_attr.shape[1])
+            xl = ops.mlp_rows(P["enc_node"], x)
+            el = ops.mlp_rows(P["enc_edge"], edge_attr)
+            H = P["rounds"][0].ws.out_dim if P["rounds"] else 0
+            scratch = None
+            if P["rounds"]:
+                dev = x.device
+                ps = torch.empty((n, H), dtype=torch.float32, device=dev)
+                pd = torch.empty((n, H), dtype=torch.float32, device=dev)
+                agg = torch.empty((n, xl.shape[1]), dtype=torch.float32, device=dev)
+                e_upd = torch.empty_like(el) if self.message_source == "edge" else None
+                scratch = (ps, pd, agg, e_upd)
+            for p in P["rounds"]:
+                # residual streams updated in place (reference graph_network.py:181-182)
+                xl, el = _run_round(p, xl, el, src, dst, fixed_k, self.message_source, residual=True,
+                                    x_out=xl, e_out=el, scratch=scratch)
+            out = {"acceleration": ops.mlp_rows(P["dec_acc"], xl), "temp_rate": ops.mlp_rows(P["dec_tr"], xl)}
+            if want_latents:
+                out["x_latent"], out["edge_latent"] = xl, el
+        return out

@@ -1,0 +1,218 @@
+"""Tensor-level wrappers over the C ABI (one Python function per ``cgnn_*`` op).
+
+Every function validates devices/dtypes, hands raw device pointers and the
+current HIP stream to ``libcgnn_hip.so`` and raises :class:`CgnnError` on a
+non-zero status.  Outputs are torch tensors so callers keep normal ownership.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, CgnnError, Linear, Mlp, check, f32c, i32c, ptr, require_device, stream_ptr
+
+
+def _prec(p) -> int:
+    if isinstance(p, int):
+        return p
+    try:
+        return _lib.PRECISIONS[str(p).lower()]
+    except KeyError:
+        raise ValueError(f"unknown precision {p!r}; use 'fp32' or 'bf16'") from None
+
+
+class PackedLinear:
+    """A Linear layer (or a column slice of one) in MFMA-fragment order."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], precision, col0: int = 0,
+                 ncols: Optional[int] = None):
+        lib = _lib.load()
+        w = f32c(weight.detach(), "weight")
+        out_dim, ld = w.shape
+        ncols = ld - col0 if ncols is None else ncols
+        self.precision = _prec(precision)
+        self.in_dim, self.out_dim = int(ncols), int(out_dim)
+        nbytes = lib.cgnn_packed_linear_bytes(out_dim, ncols, self.precision)
+        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        check(lib.cgnn_pack_linear(w.data_ptr(), out_dim, ld, col0, ncols, self.precision, self.packed.data_ptr(),
+                                   stream_ptr(w.device)), "cgnn_pack_linear")
+        self.bias = None if bias is None else f32c(bias.detach(), "bias").clone()
+
+    def struct(self) -> Linear:
+        return Linear(self.packed.data_ptr(), ptr(self.bias), self.in_dim, self.out_dim)
+
+
+class PackedMLP:
+    """``build_mlp`` (+ optional LayerNorm) ready for the kernels."""
+
+    def __init__(self, linears: Sequence[Tuple[torch.Tensor, Optional[torch.Tensor]]],
+                 layer_norm: Optional[Tuple[torch.Tensor, torch.Tensor]], precision,
+                 first_layer_cols: Optional[Tuple[int, int]] = None):
+        nh = len(linears) - 1
+        if nh < 1 or nh > _lib.MAX_HIDDEN_LAYERS:
+            raise CgnnError(f"mlp_num_hidden_layers={nh} outside [1, {_lib.MAX_HIDDEN_LAYERS}]")
+        self.precision = _prec(precision)
+        self.layers: List[PackedLinear] = []
+        for i, (w, b) in enumerate(linears):
+            if i == 0 and first_layer_cols is not None:
+                self.layers.append(PackedLinear(w, b, self.precision, first_layer_cols[0], first_layer_cols[1]))
+            else:
+                self.layers.append(PackedLinear(w, b, self.precision))
+        self.gamma = self.beta = None
+        if layer_norm is not None:
+            self.gamma = f32c(layer_norm[0].detach(), "ln weight").clone()
+            self.beta = f32c(layer_norm[1].detach(), "ln bias").clone()
+        self.num_hidden_layers = nh
+        self.in_dim = self.layers[0].in_dim
+        self.hidden = self.layers[0].out_dim
+        self.out_dim = self.layers[-1].out_dim
+        m = Mlp()
+        m.precision = self.precision
+        m.num_hidden_layers = nh
+        for i, L in enumerate(self.layers):
+            m.layer[i] = L.struct()
+        m.ln_gamma = ptr(self.gamma)
+        m.ln_beta = ptr(self.beta)
+        self._struct = m
+
+    def struct(self) -> Mlp:
+        return self._struct
+
+
+def mlp_rows(mlp: PackedMLP, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x = f32c(x, "x")
+    n = x.shape[0]
+    if x.dim() != 2 or x.shape[1] != mlp.in_dim:
+        raise CgnnError(f"mlp_rows: input is {tuple(x.shape)}, the MLP expects [n, {mlp.in_dim}]")
+    y = out if out is not None else torch.empty((n, mlp.out_dim), dtype=torch.float32, device=x.device)
+    check(_lib.load().cgnn_mlp_rows(C.byref(mlp.struct()), x.data_ptr(), n, x.stride(0), y.data_ptr(), y.stride(0),
+                                    stream_ptr(x.device)), "cgnn_mlp_rows")
+    return y
+
+
+def project_nodes(ws: Optional[PackedLinear], wd: Optional[PackedLinear], x: torch.Tensor,
+                  ps: Optional[torch.Tensor] = None, pd: Optional[torch.Tensor] = None):
+    x = f32c(x, "x")
+    n = x.shape[0]
+    ref = ws if ws is not None else wd
+    if ws is not None and ps is None:
+        ps = torch.empty((n, ws.out_dim), dtype=torch.float32, device=x.device)
+    if wd is not None and pd is None:
+        pd = torch.empty((n, wd.out_dim), dtype=torch.float32, device=x.device)
+    s1 = ws.struct() if ws is not None else None
+    s2 = wd.struct() if wd is not None else None
+    check(_lib.load().cgnn_project_nodes(C.byref(s1) if s1 is not None else None,
+                                         C.byref(s2) if s2 is not None else None, ref.precision, x.data_ptr(), n,
+                                         ptr(ps) if ws is not None else None, ptr(pd) if wd is not None else None,
+                                         stream_ptr(x.device)), "cgnn_project_nodes")
+    return ps, pd
+
+
+def edge_block(mlp: PackedMLP, ps: torch.Tensor, pd: torch.Tensor, src: torch.Tensor, dst: torch.Tensor,
+               e_in: torch.Tensor, e_out: Optional[torch.Tensor] = None, e_upd: Optional[torch.Tensor] = None,
+               residual: bool = True) -> torch.Tensor:
+    e_in = f32c(e_in, "edge latents")
+    src, dst = i32c(src, "src"), i32c(dst, "dst")
+    ne, latent = e_in.shape
+    if e_out is None:
+        e_out = torch.empty_like(e_in)
+    for t, name in ((ps, "ps"), (pd, "pd"), (e_out, "e_out")):
+        require_device(t, name)
+        if not t.is_contiguous() or t.dtype != torch.float32:
+            raise CgnnError(f"edge_block: {name} must be contiguous float32")
+    if src.numel() != ne or dst.numel() != ne:
+        raise CgnnError("edge_block: src/dst length does not match the edge latents")
+    check(_lib.load().cgnn_edge_block(C.byref(mlp.struct()), ps.data_ptr(), pd.data_ptr(), src.data_ptr(),
+                                      dst.data_ptr(), ne, e_in.data_ptr(), e_out.data_ptr(), ptr(e_upd),
+                                      1 if residual else 0, latent, stream_ptr(e_in.device)), "cgnn_edge_block")
+    return e_out
+
+
+def aggregate(table: torch.Tensor, gather: Optional[torch.Tensor], dst: Optional[torch.Tensor], num_nodes: int,
+              fixed_k: int = 0, num_edges: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    table = f32c(table, "table")
+    width = table.shape[1]
+    if gather is not None:
+        gather = i32c(gather, "gather")
+    if dst is not None:
+        dst = i32c(dst, "dst")
+    if num_edges is None:
+        num_edges = gather.numel() if gather is not None else (dst.numel() if dst is not None else table.shape[0])
+    if out is None:
+        out = torch.empty((num_nodes, width), dtype=torch.float32, device=table.device)
+    check(_lib.load().cgnn_aggregate(table.data_ptr(), ptr(gather), ptr(dst), num_edges, fixed_k, num_nodes, width,
+                                     out.data_ptr(), stream_ptr(table.device)), "cgnn_aggregate")
+    return out
+
+
+def node_block(mlp: PackedMLP, w_x: PackedLinear, w_agg: PackedLinear, x: torch.Tensor, agg: torch.Tensor,
+               x_out: Optional[torch.Tensor] = None, residual: bool = True) -> torch.Tensor:
+    x, agg = f32c(x, "x"), f32c(agg, "agg")
+    n, latent = x.shape
+    if x_out is None:
+        x_out = torch.empty_like(x)
+    sx, sa = w_x.struct(), w_agg.struct()
+    check(_lib.load().cgnn_node_block(C.byref(mlp.struct()), C.byref(sx), C.byref(sa), x.data_ptr(), agg.data_ptr(),
+                                      n, x_out.data_ptr(), 1 if residual else 0, latent, stream_ptr(x.device)),
+          "cgnn_node_block")
+    return x_out
+
+
+def knn_periodic(pos: torch.Tensor, box_size: float, k: int, query_ids: Optional[torch.Tensor] = None,
+                 want_edge_attr: bool = True, want_order: bool = False):
+    """Returns ``(senders int32 [nq*k], edge_attr float32 [nq*k, 4] | None, order int32 [n] | None)``."""
+    lib = _lib.load()
+    pos = f32c(pos, "pos")
+    if pos.dim() != 2 or pos.shape[1] != 3:
+        raise CgnnError(f"knn_periodic: pos must be [n, 3], got {tuple(pos.shape)}")
+    n = pos.shape[0]
+    if query_ids is not None:
+        query_ids = i32c(query_ids, "query_ids")
+        nq = query_ids.numel()
+    else:
+        nq = n
+    ws_bytes = lib.cgnn_knn_workspace_bytes(n, k)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pos.device)
+    senders = torch.empty(nq * k, dtype=torch.int32, device=pos.device)
+    edge_attr = torch.empty((nq * k, 4), dtype=torch.float32, device=pos.device) if want_edge_attr else None
+    st = stream_ptr(pos.device)
+    check(lib.cgnn_knn_periodic(pos.data_ptr(), n, float(box_size), k, ptr(query_ids), nq, senders.data_ptr(),
+                                ptr(edge_attr), ws.data_ptr(), ws_bytes, st), "cgnn_knn_periodic")
+    order = None
+    if want_order:
+        order = torch.empty(n, dtype=torch.int32, device=pos.device)
+        check(lib.cgnn_knn_sorted_order(ws.data_ptr(), n, order.data_ptr(), st), "cgnn_knn_sorted_order")
+    return senders, edge_attr, order
+
+
+def segment_colsum(acc: torch.Tensor, batch: Optional[torch.Tensor], num_graphs: int) -> torch.Tensor:
+    acc = f32c(acc, "acc")
+    if batch is not None:
+        batch = i32c(batch, "batch")
+    n, width = acc.shape
+    sums = torch.empty((num_graphs, width), dtype=torch.float64, device=acc.device)
+    check(_lib.load().cgnn_segment_colsum(acc.data_ptr(), ptr(batch), n, width, num_graphs, sums.data_ptr(),
+                                          stream_ptr(acc.device)), "cgnn_segment_colsum")
+    return sums
+
+
+def gather_rows(table: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    table, idx = f32c(table, "table"), i32c(idx, "idx")
+    if out is None:
+        out = torch.empty((idx.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
+    check(_lib.load().cgnn_gather_rows(table.data_ptr(), idx.data_ptr(), idx.numel(), table.shape[1], out.data_ptr(),
+                                       stream_ptr(table.device)), "cgnn_gather_rows")
+    return out
+
+
+def scatter_rows(rows: torch.Tensor, idx: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    rows, idx = f32c(rows, "rows"), i32c(idx, "idx")
+    require_device(table, "table")
+    if not table.is_contiguous() or table.dtype != torch.float32:
+        raise CgnnError("scatter_rows: table must be contiguous float32")
+    check(_lib.load().cgnn_scatter_rows(rows.data_ptr(), idx.data_ptr(), idx.numel(), table.shape[1],
+                                        table.data_ptr(), stream_ptr(table.device)), "cgnn_scatter_rows")
+    return table

@@ -1,0 +1,165 @@
+/*
+ * cgnn.h -- C ABI of the MI355X (gfx950) Interaction-Network message-passing engine.
+ *
+ * The reference (mattpan-peregrinus/Cosmology_GNN_Simulation) has no FFI: its hot
+ * path is the Python API of graph_network.py / data_utils.py, whose native work
+ * happens inside third-party ops.  Every
+ * entry point below replaces one of those call sites; the reference file:line it
+ * stands in for is given with each declaration.  The Python side
+ * (cosmology_gnn_simulation_amd/graph_network.py, data_utils.py) binds these
+ * symbols with ctypes; INTEGRATION.md shows the stub a reference maintainer adds.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless the
+ *    parameter name ends in _host;
+ *  - tensors are dense row-major float32; index arrays are int32;
+ *  - no allocation, no ownership transfer: scratch is a caller-provided workspace
+ *    whose size comes from the matching *_workspace_bytes() query;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *  - return 0 on success, a negative cgnn_status otherwise; cgnn_last_error()
+ *    returns a thread-local message for the last failure.
+ */
+#ifndef CGNN_H_
+#define CGNN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGNN_VERSION 100          /* 0.1.0 */
+#define CGNN_MAX_HIDDEN_LAYERS 6  /* mlp_num_hidden_layers upper bound */
+
+typedef enum {
+    CGNN_OK = 0,
+    CGNN_ERR_INVALID_ARG = -1,  /* null pointer, negative size, bad enum        */
+    CGNN_ERR_UNSUPPORTED = -2,  /* shape outside the compiled specialisations    */
+    CGNN_ERR_WORKSPACE = -3,    /* workspace too small                           */
+    CGNN_ERR_HIP = -4           /* a HIP runtime call or kernel launch failed    */
+} cgnn_status;
+
+typedef enum {
+    CGNN_F32 = 0,   /* f32 operands, v_mfma_f32_32x32x2_f32, exact f32 (parity mode) */
+    CGNN_BF16 = 1   /* bf16 operands, v_mfma_f32_32x32x16_bf16, f32 accumulate       */
+} cgnn_precision;
+
+/* One Linear layer, weights already in MFMA-fragment order (cgnn_pack_linear). */
+typedef struct {
+    const void* w;      /* packed weights, cgnn_packed_linear_bytes() long */
+    const float* b;     /* bias [out_dim] (natural order), may be NULL      */
+    int32_t in_dim;     /* logical K                                        */
+    int32_t out_dim;    /* logical number of outputs                        */
+} cgnn_linear;
+
+/*
+ * build_mlp(hidden, nh, out) [+ LayerNorm(out)]  (reference graph_network.py:15-32,
+ * :133-135): nh hidden layers Linear+ReLU, a final Linear, optional LayerNorm
+ * (eps 1e-5, biased variance, affine).
+ */
+typedef struct {
+    int32_t precision;                 /* cgnn_precision of the packed weights   */
+    int32_t num_hidden_layers;         /* nh >= 1                                 */
+    cgnn_linear layer[CGNN_MAX_HIDDEN_LAYERS + 1]; /* nh hidden + 1 output layer   */
+    const float* ln_gamma;             /* [out_dim] or NULL = no LayerNorm        */
+    const float* ln_beta;              /* [out_dim] or NULL                       */
+} cgnn_mlp;
+
+/* ---- library queries -------------------------------------------------------- */
+int cgnn_version(void);
+const char* cgnn_arch(void);           /* "gfx950" */
+const char* cgnn_last_error(void);
+
+/* ---- weight packing (host-side nn.Linear.weight [out,in] -> MFMA fragments) -- */
+/* Packs columns [col0, col0+ncols) of the row-major weight w[out_dim, ld]:
+ * the column slice is how the first edge/node layer is split into its sender /
+ * receiver / edge (resp. node / aggregate) blocks, following the concatenation
+ * order of reference graph_network.py:89 and :94. */
+size_t cgnn_packed_linear_bytes(int32_t out_dim, int32_t ncols, int32_t precision);
+int cgnn_pack_linear(const float* w, int32_t out_dim, int32_t ld, int32_t col0, int32_t ncols,
+                     int32_t precision, void* packed, void* stream);
+
+/* ---- K4/K10: row-wise MLP (+LayerNorm): encoders and decoders ----------------
+ * y[n, out] = MLP(x[n, in]) ; reference graph_network.py:54,57 (encoder),
+ * :158-159 (decoders).  ld_x / ld_y are row strides in floats. */
+int cgnn_mlp_rows(const cgnn_mlp* mlp, const float* x, int64_t n, int32_t ld_x,
+                  float* y, int32_t ld_y, void* stream);
+
+/* ---- first-layer split: per-node projections consumed by cgnn_edge_block ------
+ * ps[n,H] = x[n,D] * Ws^T ; pd[n,H] = x[n,D] * Wd^T + b1, where [Ws|Wd|We] is the
+ * column split of the edge model's first Linear (reference graph_network.py:89-90:
+ * cat([x[src], x[dest], edge_attr])).  Either output may be NULL. */
+int cgnn_project_nodes(const cgnn_linear* ws, const cgnn_linear* wd, int32_t precision,
+                       const float* x, int64_t n, float* ps, float* pd, void* stream);
+
+/* ---- K5+K6+K9: fused edge update ---------------------------------------------
+ * For every edge e = (src[e] -> dst[e]):
+ *   u   = LayerNorm(MLP(cat[x[src], x[dst], e_in[e]]))      graph_network.py:89-90
+ *   e_out[e] = e_in[e] + u  (residual != 0, graph_network.py:182)  or  u
+ *   e_upd[e] = u            (if e_upd != NULL; feeds message_source="edge")
+ * with the first layer evaluated as ps[src] + pd[dst] + e_in * We^T.
+ * mlp->layer[0] holds We (in_dim = D); e_out may alias e_in. */
+int cgnn_edge_block(const cgnn_mlp* mlp, const float* ps, const float* pd,
+                    const int32_t* src, const int32_t* dst, int64_t num_edges,
+                    const float* e_in, float* e_out, float* e_upd, int32_t residual,
+                    int32_t latent, void* stream);
+
+/* ---- K7: aggregation (PyG propagate, aggr='add') ------------------------------
+ * out[i] = sum over edges e with dst[e]==i of table[gather ? gather[e] : e].
+ *  - fixed_k > 0: edges are receiver-sorted with exactly fixed_k edges per
+ *    receiver (the layout data_utils.preprocess produces): segmented
+ *    gather-sum, no atomics, bit-reproducible; dst is ignored (may be NULL).
+ *  - fixed_k == 0: general edge list: out is zeroed, then run-length-reduced
+ *    float atomics keyed by dst (sum order not reproducible).
+ * reference graph_network.py:92 -> torch_geometric MessagePassing.propagate. */
+int cgnn_aggregate(const float* table, const int32_t* gather, const int32_t* dst,
+                   int64_t num_edges, int32_t fixed_k, int64_t num_nodes, int32_t width,
+                   float* out, void* stream);
+
+/* ---- K8+K9: fused node update --------------------------------------------------
+ *   u = LayerNorm(MLP(cat[x, agg]))                          graph_network.py:94-96
+ *   x_out = x + u (residual != 0, graph_network.py:181) or u
+ * w_x / w_agg are the column split of the node model's first Linear; the rest of
+ * the MLP (hidden layers 1.., output layer, LayerNorm) is in `mlp` with
+ * mlp->layer[0] ignored.  x_out may alias x. */
+int cgnn_node_block(const cgnn_mlp* mlp, const cgnn_linear* w_x, const cgnn_linear* w_agg,
+                    const float* x, const float* agg, int64_t n, float* x_out,
+                    int32_t residual, int32_t latent, void* stream);
+
+/* ---- K1+K2+K3: periodic k-NN graph + edge features -----------------------------
+ * For each query particle q (all n, or query_ids[0..nq) when non-NULL) the k
+ * nearest of the 27 periodic images of all particles, ordered by (float32 squared
+ * distance, image index); the particle itself comes first (distance 0).
+ *   senders[i*k + j]      = index in [0,n) of the j-th neighbour of query i
+ *   edge_attr[(i*k+j)*4..] = (pos[sender] - pos[query], |.|)   NOT minimum-image
+ * reference data_utils.py:9-33 (27 shifts), :148-152 (torch_cluster.knn + swap +
+ * mapping), :162-164 (edge features). edge_attr may be NULL. */
+size_t cgnn_knn_workspace_bytes(int64_t n, int32_t k);
+int cgnn_knn_periodic(const float* pos, int64_t n, float box_size, int32_t k,
+                      const int32_t* query_ids, int64_t nq,
+                      int32_t* senders, float* edge_attr,
+                      void* workspace, size_t workspace_bytes, void* stream);
+/* Optional by-product of the last cgnn_knn_periodic on this workspace: the
+ * cell-sorted particle order (a locality-improving permutation), perm[i] = original
+ * index of the i-th particle in sorted order. */
+int cgnn_knn_sorted_order(const void* workspace, int64_t n, int32_t* perm, void* stream);
+
+/* ---- K11: momentum-conservation term ------------------------------------------
+ * sums[g, c] = sum_{i: batch[i]==g} acc[i, c] in float64 (batch sorted ascending,
+ * NULL = one graph); reference train.py:107-118.  sums is [num_graphs, width] f64,
+ * zeroed by the call. */
+int cgnn_segment_colsum(const float* acc, const int32_t* batch, int64_t n, int32_t width,
+                        int32_t num_graphs, double* sums, void* stream);
+
+/* ---- halo pack / unpack (multi-GPU ghost rows) and row permutation -------------
+ * out[i, :] = table[idx[i], :]   and   table[idx[i], :] = rows[i, :]  */
+int cgnn_gather_rows(const float* table, const int32_t* idx, int64_t n_idx, int32_t width,
+                     float* out, void* stream);
+int cgnn_scatter_rows(const float* rows, const int32_t* idx, int64_t n_idx, int32_t width,
+                      float* table, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGNN_H_ */

@@ -1,0 +1,367 @@
+"""CPU oracle: a plain torch/numpy restatement of the reference hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``cosmology_gnn_simulation_amd/`` may
+import this module.  The only legal importers are ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py``; there
+it is the checker (or the timed CPU baseline), never the thing shipped.
+
+What it restates (all citations are into the read-only reference checkout):
+
+* ``graph_network.py:15-32``   build_mlp            -> :func:`mlp`
+* ``graph_network.py:133-135`` MLP + LayerNorm      -> :func:`mlp_ln`
+* ``graph_network.py:52-64``   GraphIndependent     -> :func:`graph_independent`
+* ``graph_network.py:83-101``  InteractionNetwork   -> :func:`interaction_network`
+* ``graph_network.py:154-183`` EncodeProcessDecode  -> :func:`encode_process_decode`
+* ``data_utils.py:9-33``       27-image extension   -> :func:`extend_positions`
+* ``data_utils.py:36-70``      random-walk noise    -> :func:`position_noise`, :func:`temperature_noise`
+* ``data_utils.py:72-228``     preprocess           -> :func:`preprocess`
+* ``one_step_test.py:84-111``  one-step integrator  -> :func:`one_step`
+* ``train.py:107-118``         momentum term        -> :func:`momentum_conservation_loss`
+
+Third-party arithmetic that is NOT in the reference checkout and is restated
+here from its published behaviour:
+
+* torch-geometric 2.6.1 ``MessagePassing.propagate`` with the default
+  ``message(x_j) = x_j``, ``flow='source_to_target'``, ``aggr='add'``:
+  ``out = zeros(N, D).scatter_add_(0, edge_index[1], x[edge_index[0]])``.
+  The reference never overrides ``message`` (graph_network.py:67-101), so the
+  ``edge_attr=`` keyword at :92 is collected and dropped.  ``message_source``
+  below selects this reference-faithful behaviour (``"x_j"``) or the
+  Interaction-Network variant the prose describes (``"edge"``).
+* torch-cluster 1.6.3 ``knn(x, y, k)`` (nanoflann, float32 L2): for every row of
+  ``y`` the ``k`` nearest rows of ``x``, nearest first; returns
+  ``[2, |y|*k]`` with row 0 = y index (ascending), row 1 = x index.
+
+Pinning status: the reference ships no tests, fixtures or golden vectors.  The
+restatement is pinned against outputs of the reference's own source lines run in
+the build container behind stand-ins for the two absent packages
+(``oracle/reference_shim.py`` + ``oracle/make_golden.py`` ->
+``tests/golden/*.npz``).  The semantics of the stand-ins themselves (the two
+bullets above) are unpinned.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+Tensor = torch.Tensor
+StateDict = Dict[str, Tensor]
+
+
+# --------------------------------------------------------------------------
+# MLPs  (graph_network.py:15-32, :133-135)
+# --------------------------------------------------------------------------
+
+def mlp(sd: StateDict, prefix: str, x: Tensor, num_hidden_layers: int) -> Tensor:
+    """``Linear -> ReLU`` repeated ``num_hidden_layers`` times, then a final
+    ``Linear``.  ``nn.Sequential`` numbering puts the Linears at even indices
+    (graph_network.py:24-31): ``{prefix}.0``, ``{prefix}.2``, ...
+    """
+    h = x
+    for i in range(num_hidden_layers):
+        h = torch.relu(torch.nn.functional.linear(h, sd[f"{prefix}.{2 * i}.weight"], sd[f"{prefix}.{2 * i}.bias"]))
+    j = 2 * num_hidden_layers
+    return torch.nn.functional.linear(h, sd[f"{prefix}.{j}.weight"], sd[f"{prefix}.{j}.bias"])
+
+
+def mlp_ln(sd: StateDict, prefix: str, x: Tensor, num_hidden_layers: int) -> Tensor:
+    """``Sequential(mlp, LayerNorm(latent))`` (graph_network.py:133-135):
+    sub-module 0 is the MLP, sub-module 1 the LayerNorm (eps 1e-5, affine,
+    biased variance: torch defaults)."""
+    y = mlp(sd, f"{prefix}.0", x, num_hidden_layers)
+    w, b = sd[f"{prefix}.1.weight"], sd[f"{prefix}.1.bias"]
+    return torch.nn.functional.layer_norm(y, (y.shape[-1],), w, b, 1e-5)
+
+
+# --------------------------------------------------------------------------
+# Graph modules
+# --------------------------------------------------------------------------
+
+def graph_independent(sd: StateDict, prefix: str, x: Tensor, edge_attr: Optional[Tensor], nh: int):
+    """graph_network.py:52-64: independent node / edge encoders."""
+    xo = mlp_ln(sd, f"{prefix}.node_model", x, nh)
+    eo = mlp_ln(sd, f"{prefix}.edge_model", edge_attr, nh) if edge_attr is not None else None
+    return xo, eo
+
+
+def propagate_add(x: Tensor, edge_index: Tensor, messages: Optional[Tensor] = None) -> Tensor:
+    """PyG ``propagate`` with ``aggr='add'`` (see module docstring).
+    ``messages=None`` means the default ``message(x_j) = x_j``."""
+    src, dst = edge_index[0], edge_index[1]
+    msg = x.index_select(0, src) if messages is None else messages
+    out = x.new_zeros((x.shape[0], msg.shape[1]))
+    out.scatter_add_(0, dst.view(-1, 1).expand_as(msg), msg)
+    return out
+
+
+def interaction_network(sd: StateDict, prefix: str, x: Tensor, edge_index: Tensor, edge_attr: Tensor,
+                        nh: int, message_source: str = "x_j") -> Tuple[Tensor, Tensor]:
+    """graph_network.py:83-101.  Returns ``(updated_node, updated_edge)`` with no
+    residual (the residual lives in the caller, :181-182)."""
+    if edge_attr is None:
+        raise ValueError("edge_attr must not be None in InteractionNetwork")
+    src, dst = edge_index[0], edge_index[1]
+    edge_in = torch.cat([x[src], x[dst], edge_attr], dim=-1)          # :89 (sender, receiver, edge)
+    new_e = mlp_ln(sd, f"{prefix}.edge_model", edge_in, nh)           # :90
+    if message_source == "x_j":
+        agg = propagate_add(x, edge_index)                            # :92 with PyG's default message
+    elif message_source == "edge":
+        agg = propagate_add(x, edge_index, new_e)
+    else:
+        raise ValueError(message_source)
+    node_in = torch.cat([x, agg], dim=-1)                             # :94
+    new_x = mlp_ln(sd, f"{prefix}.node_model", node_in, nh)           # :96
+    return new_x, new_e
+
+
+def encode_process_decode(sd: StateDict, x: Tensor, edge_index: Tensor, edge_attr: Tensor,
+                          num_hidden_layers: int, num_message_passing_steps: int,
+                          message_source: str = "x_j", return_latents: bool = False):
+    """graph_network.py:154-183: encoder, L residual message-passing rounds,
+    two decoders.  Returns the reference's dict (plus latents on request)."""
+    nh = num_hidden_layers
+    xl, el = graph_independent(sd, "encoder", x, edge_attr, nh)       # :166-175
+    for i in range(num_message_passing_steps):                        # :177-183
+        dx, de = interaction_network(sd, f"processor.{i}", xl, edge_index, el, nh, message_source)
+        xl = xl + dx
+        el = el + de
+    out = {
+        "acceleration": mlp(sd, "decoder_acc", xl, nh),               # :158
+        "temp_rate": mlp(sd, "decoder_temp_rate", xl, nh),            # :159
+    }
+    if return_latents:
+        out["x_latent"] = xl
+        out["edge_latent"] = el
+    return out
+
+
+# --------------------------------------------------------------------------
+# Graph build  (data_utils.py)
+# --------------------------------------------------------------------------
+
+def shift_table(box_size: float) -> Tensor:
+    """27 shifts in ``cartesian_prod([-L,0,L]^3)`` order (data_utils.py:24-25):
+    first coordinate slowest, centre (0,0,0) is entry 13."""
+    v = torch.tensor([-box_size, 0.0, box_size], dtype=torch.float32)
+    return torch.cartesian_prod(v, v, v)
+
+
+def extend_positions(positions: Tensor, box_size: float) -> Tuple[Tensor, Tensor]:
+    """data_utils.py:9-33 for d=3: ``ext[s*N + i] = fl32(pos[i] + shift[s])``,
+    ``mapping[s*N + i] = i``."""
+    n = positions.shape[0]
+    sh = shift_table(float(box_size))
+    ext = (positions.unsqueeze(0) + sh.unsqueeze(1)).reshape(-1, 3)
+    mapping = torch.arange(n).repeat(sh.shape[0])
+    return ext, mapping
+
+
+def _sqdist_f32(ext: np.ndarray, q: np.ndarray) -> np.ndarray:
+    """float32 squared distance with one rounding per operation, summed x,y,z in
+    order: nanoflann's L2 adaptor remainder loop for dim=3 (no FMA)."""
+    d = (ext - q).astype(np.float32)
+    sq = (d * d).astype(np.float32)
+    return ((sq[..., 0] + sq[..., 1]).astype(np.float32) + sq[..., 2]).astype(np.float32)
+
+
+def knn_extended(ext: Tensor, queries: Tensor, k: int, pad: int = 8) -> Tensor:
+    """``torch_cluster.knn(ext, queries, k)`` restated: exact k nearest rows of
+    ``ext`` for each query, ordered by (float32 squared distance, ext index).
+    Returns ``[2, Q*k]`` int64: row 0 = query index, row 1 = ext index.
+
+    A double-precision cKDTree proposes ``k+pad`` candidates; they are re-ranked
+    with the float32 arithmetic above, so the result is exact unless more than
+    ``pad`` points tie with the k-th neighbour to float64 precision.
+    """
+    from scipy.spatial import cKDTree
+
+    e = ext.detach().cpu().numpy().astype(np.float32)
+    q = queries.detach().cpu().numpy().astype(np.float32)
+    kk = min(k + pad, e.shape[0])
+    tree = cKDTree(e.astype(np.float64))
+    _, cand = tree.query(q.astype(np.float64), k=kk, workers=-1)
+    cand = cand.reshape(q.shape[0], kk).astype(np.int64)
+    d2 = _sqdist_f32(e[cand], q[:, None, :])
+    order = np.lexsort((cand, d2), axis=1)[:, :k]            # primary d2, secondary ext index
+    nbr = np.take_along_axis(cand, order, axis=1)
+    rows = np.repeat(np.arange(q.shape[0], dtype=np.int64), k)
+    return torch.from_numpy(np.stack([rows, nbr.reshape(-1)], axis=0))
+
+
+def knn_periodic(pos: Tensor, box_size: float, k: int) -> Tuple[Tensor, Tensor]:
+    """data_utils.py:148-164: periodic k-NN graph and edge features.
+
+    Returns ``edge_index`` int64 ``[2, N*k]`` (row 0 sender = mapped neighbour,
+    row 1 receiver = query; receiver-sorted, self first) and ``edge_attr``
+    ``[N*k, 4]`` = (pos[snd] - pos[rcv], norm).  The displacement uses the
+    *mapped* sender, i.e. it is not minimum-image."""
+    ext, mapping = extend_positions(pos, box_size)
+    ei = knn_extended(ext, pos, k)
+    ei = torch.stack([ei[1], ei[0]], dim=0)                   # :150
+    snd = mapping[ei[0]]                                      # :151
+    rcv = mapping[ei[1]]                                      # :152 (identity on queries < N)
+    disp = pos[snd] - pos[rcv]                                # :162
+    dist = torch.norm(disp, dim=-1, keepdim=True)             # :163
+    return torch.stack([snd, rcv], dim=0), torch.cat((disp, dist), dim=-1)
+
+
+def _min_image_(d: Tensor, box_size: float) -> Tensor:
+    """In-place boundary-crossing correction of data_utils.py:41-42,104-105."""
+    d[d < -1 * box_size / 2] += box_size
+    d[d > box_size / 2] -= box_size
+    return d
+
+
+def position_noise(position_seq: Tensor, noise_std: float, box_size: float, dt: float,
+                   generator: Optional[torch.Generator] = None) -> Tensor:
+    """data_utils.py:36-54.  ``position_seq`` is ``[N, W, 3]``.  Draws from the
+    RNG even when ``noise_std == 0`` (:47)."""
+    p = position_seq.float()
+    disp = _min_image_(p[:, 1:] - p[:, :-1], box_size)
+    vel = disp / dt
+    steps = vel.size(1)
+    draw = torch.randn(vel.shape, dtype=torch.float32, generator=generator) if generator is not None \
+        else torch.randn_like(vel, dtype=torch.float32)
+    vn = (draw * (noise_std / (steps ** 0.5))).cumsum(dim=1)
+    pn = vn.cumsum(dim=1) * dt
+    return torch.cat((torch.zeros_like(pn)[:, 0:1], pn), dim=1)
+
+
+def temperature_noise(temperature_seq: Tensor, noise_std: float, temp_rate_std, dt: float,
+                      generator: Optional[torch.Generator] = None) -> Tensor:
+    """data_utils.py:57-70."""
+    t = temperature_seq.float()
+    rate = (t[:, 1:] - t[:, :-1]) / dt
+    steps = rate.size(1)
+    draw = torch.randn(rate.shape, dtype=torch.float32, generator=generator) if generator is not None \
+        else torch.randn_like(rate, dtype=torch.float32)
+    rn = (draw * (noise_std * temp_rate_std / (steps ** 0.5))).cumsum(dim=1)
+    tn = rn.cumsum(dim=1) * dt
+    return torch.cat((torch.zeros_like(tn)[:, 0:1], tn), dim=1)
+
+
+def preprocess(position_seq: Tensor, temperature_seq: Tensor, metadata: dict,
+               target_position: Optional[Tensor] = None, target_temperature: Optional[Tensor] = None,
+               noise_std: float = 0.0, num_neighbors: int = 16, dt=None, box_size=None) -> dict:
+    """data_utils.py:72-228 restated; returns a plain dict with the attribute
+    names of the reference's ``Data`` (:218-227).  Inputs are ``[W, N, 3]`` and
+    ``[W, N, 1]`` as the callers pass them (one_step_test.py:54-65)."""
+    dt = float(dt)
+    box_size = float(box_size)
+    pos = position_seq.float().permute(1, 0, 2)                         # :86 -> [N, W, 3]
+    tmp = temperature_seq.float()
+    if tmp.shape[0] == pos.shape[1] and tmp.shape[1] == pos.shape[0]:  # :87-88
+        tmp = tmp.permute(1, 0, 2)
+    if target_position is not None:
+        target_position = target_position.float()
+
+    pn = position_noise(pos, noise_std, box_size, dt)                   # :91
+    pos = torch.remainder(pos + pn, box_size)                           # :92
+    trs = torch.tensor(metadata["temp_rate_std"], dtype=torch.float32)
+    tn = temperature_noise(tmp, noise_std, trs, dt)                     # :96
+    tmp = tmp + tn
+
+    recent = pos[:, -1]                                                 # :100
+    vel = _min_image_(pos[:, 1:] - pos[:, :-1], box_size) / dt          # :102-107
+    recent_t = tmp[:, -1]                                               # :110
+
+    if target_temperature is not None:                                  # :113-124
+        target_temperature = target_temperature.float()
+        if target_temperature.dim() == 3:
+            target_temperature = target_temperature.permute(1, 0, 2).squeeze(1)
+        elif target_temperature.dim() == 2 and target_temperature.shape[1] != 1:
+            target_temperature = target_temperature.reshape(-1, 1)
+        if target_temperature.shape != recent_t.shape and target_temperature.numel() == recent_t.numel():
+            target_temperature = target_temperature.reshape(recent_t.shape)
+
+    vm = torch.tensor(metadata["vel_mean"], dtype=torch.float32)
+    vs = torch.tensor(metadata["vel_std"], dtype=torch.float32)
+    tm = torch.tensor(metadata["temp_mean"], dtype=torch.float32)
+    ts = torch.tensor(metadata["temp_std"], dtype=torch.float32)
+    nvel = (vel - vm) / vs                                              # :129
+    ntmp = (tmp - tm) / ts                                              # :134
+    x = torch.cat((nvel.reshape(nvel.size(0), -1), ntmp.reshape(ntmp.size(0), -1)), dim=-1)  # :138-145
+
+    edge_index, edge_attr = knn_periodic(recent, box_size, num_neighbors)  # :148-164
+
+    y_acc = None
+    y_tr = None
+    if target_position is not None:                                     # :170-194
+        tp = target_position
+        if tp.dim() == 3:
+            tp = tp.permute(1, 0, 2).squeeze(1)
+        elif tp.dim() == 2 and tp.shape[0] != recent.shape[0]:
+            tp = tp.reshape(-1, 3)
+        tp = tp + pn[:, -1]
+        nd = _min_image_(tp - recent, box_size)
+        y_acc = ((nd / dt) - vel[:, -1]) / dt
+        am = torch.tensor(metadata["acc_mean"], dtype=torch.float32)
+        as_ = torch.tensor(metadata["acc_std"], dtype=torch.float32)
+        y_acc = ((y_acc - am) / as_).float()
+    if target_temperature is not None:                                  # :196-213
+        tt = target_temperature
+        if tt.dim() == 3:
+            tt = tt.squeeze(1)
+        tt = tt + tn[:, -1]
+        y_tr = (tt - recent_t) / dt
+        trm = torch.tensor(metadata["temp_rate_mean"], dtype=torch.float32)
+        y_tr = ((y_tr - trm) / trs).float()
+
+    return dict(x=x.float(), edge_index=edge_index, edge_attr=edge_attr, y_acc=y_acc, y_temp_rate=y_tr,
+                pos=recent, dt=torch.tensor([dt], dtype=torch.float32),
+                box_size=torch.tensor([box_size], dtype=torch.float32))
+
+
+# --------------------------------------------------------------------------
+# Callers' arithmetic
+# --------------------------------------------------------------------------
+
+def one_step(acc_pred: Tensor, temp_rate_pred: Tensor, coords_seq: Tensor, temp_seq: Tensor,
+             next_coords: Tensor, next_temp: Tensor, metadata: dict) -> dict:
+    """one_step_test.py:84-111: un-normalise, semi-implicit Euler, wrap, MSE."""
+    dt = metadata["dt"]
+    box = metadata["box_size"]
+    acc = acc_pred * torch.tensor(metadata["acc_std"], dtype=torch.float32) + \
+        torch.tensor(metadata["acc_mean"], dtype=torch.float32)
+    tr = temp_rate_pred * torch.tensor(metadata["temp_rate_std"], dtype=torch.float32) + \
+        torch.tensor(metadata["temp_rate_mean"], dtype=torch.float32)
+    recent_p = coords_seq[-1]
+    recent_v = (recent_p - coords_seq[-2]) / dt
+    recent_t = temp_seq[-1]
+    new_v = recent_v + acc * dt
+    new_p = torch.remainder(recent_p + new_v * dt, box)
+    new_t = recent_t + tr * dt
+    return dict(new_position=new_p, new_temp=new_t,
+                position_mse=torch.mean((new_p - next_coords) ** 2).item(),
+                temperature_mse=torch.mean((new_t - next_temp) ** 2).item())
+
+
+def momentum_conservation_loss(accelerations: Tensor, batch: Tensor, num_graphs: int, dt: float,
+                               momentum_weight: float) -> Tensor:
+    """train.py:107-118: ``w/B * sum_g || sum_{n in g} acc[n]*dt ||^2``."""
+    dv = accelerations * dt
+    total = accelerations.new_zeros(())
+    for g in range(num_graphs):
+        s = torch.sum(dv[batch == g], dim=0)
+        total = total + torch.sum(s ** 2)
+    return momentum_weight * total / num_graphs
+
+
+# --------------------------------------------------------------------------
+# CPU baseline timing helper (bench.py cpu_baseline leg)
+# --------------------------------------------------------------------------
+
+def time_forward(sd: StateDict, x: Tensor, edge_index: Tensor, edge_attr: Tensor, nh: int, steps: int,
+                 repeats: int = 1) -> float:
+    """Seconds per ``encode_process_decode`` on the host cores (min over repeats)."""
+    import time
+    best = math.inf
+    with torch.no_grad():
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            encode_process_decode(sd, x, edge_index, edge_attr, nh, steps)
+            best = min(best, time.perf_counter() - t0)
+    return best

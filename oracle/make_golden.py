@@ -1,0 +1,123 @@
+"""Generate the committed golden fixtures under ``tests/golden/``.
+
+Runs ONLY in the build container (needs the read-only reference checkout).  It
+executes the reference's own ``data_utils.preprocess`` and
+``graph_network.EncodeProcessDecode`` (through ``oracle/reference_shim.py``) on
+seeded synthetic inputs and stores inputs + outputs as ``.npz``.  It also checks
+the CPU restatement ``oracle/cpu_ref.py`` against those outputs and refuses to
+write a fixture the restatement disagrees with.
+
+    python -m oracle.make_golden            # writes tests/golden/*.npz
+
+Fixture fields are data only (inputs, weights, outputs); no reference source
+text is stored.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from cosmology_gnn_simulation_amd import synthetic  # noqa: E402
+from oracle import cpu_ref, reference_shim  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+CASES = {
+    # name: N, k, latent(=hidden), nh, L, box, seed, store_weights
+    "tiny": dict(n=256, k=8, d=32, nh=2, steps=3, box=1.0, seed=1234),
+    "tiny_k16_box25": dict(n=384, k=16, d=32, nh=1, steps=2, box=25.0, seed=1250),
+    "cfg1": dict(n=4096, k=8, d=64, nh=2, steps=5, box=1.0, seed=1235),   # BASELINE.json configs[0]
+}
+
+
+def rel(a: torch.Tensor, b: torch.Tensor) -> float:
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def run_case(name: str, c: dict) -> None:
+    gn, du = reference_shim.load()
+    torch.manual_seed(0)
+    snap = synthetic.make_snapshot(c["n"], window=5, box_size=c["box"], dt=0.01, seed=c["seed"])
+    meta = synthetic.make_metadata(box_size=c["box"], dt=0.01)
+    coords, energy = snap["Coordinates"], snap["InternalEnergy"]
+    W = 5
+    sd = synthetic.make_state_dict(c["d"], c["d"], c["nh"], c["steps"], 3, seed=7)
+
+    # ---- the reference's own lines --------------------------------------------------
+    g = du.preprocess(position_seq=coords[:W].clone(), temperature_seq=energy[:W].clone(), metadata=meta,
+                      target_position=coords[W].clone(), target_temperature=energy[W].clone(),
+                      noise_std=0.0, num_neighbors=c["k"], dt=meta["dt"], box_size=meta["box_size"])
+    model = gn.EncodeProcessDecode(latent_size=c["d"], mlp_hidden_size=c["d"], mlp_num_hidden_layers=c["nh"],
+                                   num_message_passing_steps=c["steps"], output_size=3)
+    model.load_state_dict(sd)
+    model.eval()
+    with torch.no_grad():
+        pred = model(g)
+        # one InteractionNetwork block on its own, fed the encoder output (graph_network.py:83-101)
+        lat0 = model._encode(g)
+        blk = model.processor[0](lat0)
+    acc, tr = pred["acceleration"], pred["temp_rate"]
+    # train.py:107-118 with one graph (B=1), weight 1
+    dv = acc * meta["dt"]
+    mom = float(torch.sum(torch.sum(dv, dim=0) ** 2))
+
+    # ---- the restatement must agree before anything is written ----------------------
+    r = cpu_ref.preprocess(coords[:W].clone(), energy[:W].clone(), meta, coords[W].clone(), energy[W].clone(),
+                           0.0, c["k"], meta["dt"], meta["box_size"])
+    assert torch.equal(r["edge_index"], g.edge_index), "edge_index differs"
+    for key in ("x", "edge_attr", "y_acc", "y_temp_rate", "pos"):
+        assert torch.equal(r[key], getattr(g, key)), key
+    with torch.no_grad():
+        o = cpu_ref.encode_process_decode(sd, g.x, g.edge_index, g.edge_attr, c["nh"], c["steps"], "x_j")
+        bx, be = cpu_ref.interaction_network(sd, "processor.0", lat0.x, g.edge_index, lat0.edge_attr, c["nh"])
+        oe = cpu_ref.encode_process_decode(sd, g.x, g.edge_index, g.edge_attr, c["nh"], c["steps"], "edge",
+                                           return_latents=True)
+    errs = dict(acc=rel(o["acceleration"], acc), tr=rel(o["temp_rate"], tr), blk_x=rel(bx, blk.x),
+                blk_e=rel(be, blk.edge_attr))
+    print(name, "restatement vs reference:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) <= 1e-6, errs
+    step = cpu_ref.one_step(acc, tr, coords[:W], energy[:W], coords[W], energy[W], meta)
+    m2 = float(cpu_ref.momentum_conservation_loss(acc, torch.zeros(c["n"], dtype=torch.long), 1, meta["dt"], 1.0))
+    assert abs(m2 - mom) <= 1e-6 * abs(mom), (m2, mom)
+
+    out = dict(
+        n=c["n"], k=c["k"], latent=c["d"], nh=c["nh"], steps=c["steps"], box=c["box"], dt=meta["dt"], seed=c["seed"],
+        coords=coords.numpy(), energy=energy.numpy(),
+        x=g.x.numpy(), senders=g.edge_index[0].numpy().astype(np.int32), edge_attr=g.edge_attr.numpy(),
+        y_acc=g.y_acc.numpy(), y_temp_rate=g.y_temp_rate.numpy(), pos=g.pos.numpy(),
+        acceleration=acc.numpy(), temp_rate=tr.numpy(),
+        momentum=np.float64(mom),
+        new_position=step["new_position"].numpy(), new_temp=step["new_temp"].numpy(),
+        position_mse=np.float64(step["position_mse"]), temperature_mse=np.float64(step["temperature_mse"]),
+        # message_source="edge" is NOT reference behaviour: restatement-only vectors, labelled as such
+        edge_mode_acceleration_cpuref=oe["acceleration"].numpy(), edge_mode_temp_rate_cpuref=oe["temp_rate"].numpy(),
+    )
+    if name.startswith("tiny"):     # per-stage vectors only where they stay small
+        out["enc_x"] = lat0.x.numpy()
+        out["block0_x"] = blk.x.numpy()
+    if name == "tiny":
+        out["enc_edge"] = lat0.edge_attr.numpy()
+        out["block0_edge"] = blk.edge_attr.numpy()
+    for k_, v in sd.items():
+        out["w:" + k_] = v.numpy()
+    os.makedirs(GOLDEN, exist_ok=True)
+    path = os.path.join(GOLDEN, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, f"{os.path.getsize(path) / 1e6:.2f} MB")
+
+
+def main() -> None:
+    if not reference_shim.available():
+        raise SystemExit("reference checkout not present: fixtures can only be regenerated in the build container")
+    for name, c in CASES.items():
+        run_case(name, c)
+
+
+if __name__ == "__main__":
+    main()

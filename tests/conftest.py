@@ -1,0 +1,54 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
+    g = {k: z[k] for k in z.files}
+    sd = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w:")}
+    g = {k: v for k, v in g.items() if not k.startswith("w:")}
+    g["state_dict"] = sd
+    g["metadata"] = dict(vel_mean=0.0, vel_std=1.0, acc_mean=0.0, acc_std=1.0, temp_mean=1.0, temp_std=0.5,
+                         temp_rate_mean=0.0, temp_rate_std=2.0, dt=float(g["dt"]), box_size=float(g["box"]))
+    return g
+
+
+@pytest.fixture(scope="session", params=["tiny", "tiny_k16_box25", "cfg1"])
+def golden(request):
+    return load_golden(request.param)
+
+
+@pytest.fixture(scope="session")
+def golden_tiny():
+    return load_golden("tiny")
+
+
+def edge_index_from(g):
+    n, k = int(g["n"]), int(g["k"])
+    snd = torch.from_numpy(g["senders"].astype(np.int64))
+    rcv = torch.arange(n, dtype=torch.int64).repeat_interleave(k)
+    return torch.stack([snd, rcv], dim=0)
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))

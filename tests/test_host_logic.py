@@ -1,0 +1,80 @@
+"""CPU: host-side logic of the product (no kernel launches)."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+from cosmology_gnn_simulation_amd import _lib, graph_network, synthetic
+from cosmology_gnn_simulation_amd.graph import Batch, Data
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()                                   # dlopen works without a GPU
+    header = open(os.path.join(ROOT, "include", "cgnn.h")).read()
+    declared = set(re.findall(r"\b(cgnn_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.cgnn_version() == 100
+    assert lib.cgnn_arch() == b"gfx950"
+    assert lib.cgnn_packed_linear_bytes(128, 128, _lib.BF16) == 128 * 128 * 2
+    assert lib.cgnn_packed_linear_bytes(3, 17, _lib.F32) == 32 * 32 * 4      # padded to whole 32x32 tiles
+
+
+def test_struct_layout_matches_header():
+    import ctypes as C
+    assert C.sizeof(_lib.Linear) == 24
+    assert C.sizeof(_lib.Mlp) == 8 + 7 * 24 + 16
+
+
+def test_state_dict_contract_and_load_before_forward():
+    m = graph_network.EncodeProcessDecode(128, 128, 2, 10, 3)
+    keys = list(m.state_dict().keys())
+    assert len(keys) == 188
+    shapes = synthetic.state_dict_shapes(128, 128, 2, 10, 3)
+    assert keys == list(shapes.keys())
+    sd = synthetic.make_state_dict(128, 128, 2, 10, 3)
+    m.load_state_dict(sd)                                 # before any forward (one_step_test.py:21)
+    assert tuple(m.state_dict()["processor.3.edge_model.0.0.weight"].shape) == (128, 384)
+    assert sum(v.numel() for v in sd.values()) == 1623428
+
+
+def test_no_cpu_fallback():
+    m = graph_network.EncodeProcessDecode(32, 32, 2, 1, 3)
+    m.load_state_dict(synthetic.make_state_dict(32, 32, 2, 1, 3))
+    g = Data(x=torch.zeros(4, 17), edge_index=torch.zeros(2, 8, dtype=torch.long), edge_attr=torch.zeros(8, 4))
+    with torch.no_grad(), pytest.raises(_lib.CgnnError):
+        m(g)
+
+
+def test_training_mode_is_refused_loudly():
+    m = graph_network.EncodeProcessDecode(32, 32, 2, 1, 3)
+    g = Data(x=torch.zeros(4, 17), edge_index=torch.zeros(2, 8, dtype=torch.long), edge_attr=torch.zeros(8, 4))
+    with pytest.raises(NotImplementedError):
+        m(g)
+
+
+def test_edge_attr_none_raises_value_error():
+    net = graph_network.InteractionNetwork(torch.nn.Identity(), torch.nn.Identity())
+    with pytest.raises(ValueError):
+        net(Data(x=torch.zeros(2, 4), edge_index=torch.zeros(2, 2, dtype=torch.long), edge_attr=None))
+
+
+def test_data_and_batch_surface():
+    d = Data(x=torch.zeros(3, 2), edge_index=torch.tensor([[0, 1], [1, 2]]), edge_attr=torch.zeros(2, 4))
+    assert not hasattr(d, "globals")
+    d2 = Data(x=torch.ones(2, 2), edge_index=torch.tensor([[0], [1]]), edge_attr=torch.zeros(1, 4))
+    b = Batch.from_data_list([d, d2])
+    assert b.num_graphs == 2 and b.x.shape == (5, 2)
+    assert b.edge_index.tolist() == [[0, 1, 3], [1, 2, 4]]
+    assert b.batch.tolist() == [0, 0, 0, 1, 1]
+
+
+def test_synthetic_generators_are_deterministic():
+    a = synthetic.make_snapshot(100, seed=5)
+    b = synthetic.make_snapshot(100, seed=5)
+    assert torch.equal(a["Coordinates"], b["Coordinates"]) and a["Coordinates"].shape == (6, 100, 3)
+    assert float(a["Coordinates"].min()) >= 0.0 and float(a["Coordinates"].max()) < 1.0
+    assert set(synthetic.make_metadata()) == set(synthetic.METADATA_KEYS)
