@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Headline benchmark: particle-edge updates / s of one EncodeProcessDecode forward.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward of the hot path (encoder + L message-passing rounds + decoders,
+reference graph_network.py:154-164) over a prebuilt periodic k-NN graph of a synthetic
+uniform particle box resident in HBM.  Default workload = BASELINE.json configs[2]:
+1,000,000 particles, k=16, latent=128, 10 rounds, bf16 edge MLP with f32 accumulation
+(the node path stays f32 so the outputs keep the 1e-5 gate).
+metric value = E * L * (ranks) / wall time per step, max over ranks.
+
+With N > 1 every rank owns one spatial tile of an N-times larger box (weak scaling: 1M
+particles per GPU) and ghost-node latents are exchanged over RCCL each round
+(cosmology_gnn_simulation_amd/dist.py).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--particles", type=int, default=1_000_000, help="particles per GPU")
+    p.add_argument("--neighbors", type=int, default=16)
+    p.add_argument("--latent", type=int, default=128)
+    p.add_argument("--hidden", type=int, default=None)
+    p.add_argument("--mp-steps", type=int, default=10)
+    p.add_argument("--hidden-layers", type=int, default=2)
+    p.add_argument("--edge-precision", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--node-precision", default="fp32", choices=["bf16", "fp32"])
+    p.add_argument("--message-source", default="x_j", choices=["x_j", "edge"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-particles", type=int, default=16384, help="bounded CPU-baseline sample size")
+    p.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (box share)")
+    p.add_argument("--seed", type=int, default=1236)   # 1234 + cfg index 2
+    return p.parse_args()
+
+
+def cpu_baseline(args, dev_outputs=None):
+    """The oracle (pure-torch op-for-op restatement of the reference forward) timed on this host's cores on a
+    bounded sample of the same workload: same k / latent / rounds, fewer particles."""
+    from cosmology_gnn_simulation_amd import synthetic
+    from oracle import cpu_ref
+    n, k, d, L = args.cpu_particles, args.neighbors, args.latent, args.mp_steps
+    h = args.hidden or d
+    cores = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(args.seed)
+    x = torch.randn(n, 17, generator=g)
+    # graph structure does not change the CPU cost model: random senders, fixed in-degree, self loop first
+    snd = torch.randint(0, n, (n, k), generator=g)
+    snd[:, 0] = torch.arange(n)
+    ei = torch.stack([snd.reshape(-1), torch.arange(n).repeat_interleave(k)])
+    ea = torch.randn(n * k, 4, generator=g) * 0.05
+    sd = synthetic.make_state_dict(d, h, args.hidden_layers, L, 3)
+    sec = cpu_ref.time_forward(sd, x, ei, ea, args.hidden_layers, L, repeats=1)
+    return {"value": n * k * L / sec, "unit": "edge-updates/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/cpu_ref.encode_process_decode, 1 forward, N={n} k={k} latent={d} L={L} fp32 "
+                      f"({sec:.2f} s on {cores} host threads)"}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from cosmology_gnn_simulation_amd import data_utils, graph_network, ops, synthetic
+
+    d = args.latent
+    h = args.hidden or d
+    k, L = args.neighbors, args.mp_steps
+    model = graph_network.EncodeProcessDecode(d, h, args.hidden_layers, L, 3)
+    model.load_state_dict(synthetic.make_state_dict(d, h, args.hidden_layers, L, 3))
+    model = model.to(dev).eval()
+    model.edge_precision, model.node_precision = args.edge_precision, args.node_precision
+    model.message_source = args.message_source
+
+    dist_ctx = None
+    if world > 1:
+        import torch.distributed as dist
+        from cosmology_gnn_simulation_amd import dist as cdist
+        dist.init_process_group("nccl", device_id=dev)
+        dist_ctx = cdist
+
+    # ---- synthetic input, resident in HBM before the timed region -----------------------------------
+    meta = synthetic.make_metadata()
+    t0 = time.perf_counter()
+    if world == 1:
+        snap = synthetic.make_snapshot(args.particles, seed=args.seed)
+        graph = data_utils.preprocess(snap["Coordinates"][:5], snap["InternalEnergy"][:5], meta, None, None, 0.0, k,
+                                      meta["dt"], meta["box_size"], device=dev)
+        torch.cuda.synchronize()
+        t_build = time.perf_counter() - t0
+        # graph build alone (k-NN + edge features), device resident positions
+        with ops.OpTimer() as tm:
+            data_utils.knn_graph_periodic(graph.pos, meta["box_size"], k)
+        knn_ms = tm.summary()["knn_periodic"][1]
+        n_local, e_local = graph.x.shape[0], graph.edge_index.shape[1]
+        run = lambda: model(graph)  # noqa: E731
+    else:
+        sharded = dist_ctx.build_synthetic_shard(args.particles, world, rank, k, args.seed, dev, meta)
+        torch.cuda.synchronize()
+        t_build = time.perf_counter() - t0
+        knn_ms = sharded.knn_ms
+        n_local, e_local = sharded.n_owned, sharded.n_owned * k
+        runner = dist_ctx.ShardedForward(model, sharded)
+        run = runner  # noqa: E731
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            run()
+        barrier()
+        with ops.OpTimer() as tm:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                run()
+            barrier()
+            elapsed = time.perf_counter() - t0
+        per_op = tm.summary()
+
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([float(e_local)], device=dev, dtype=torch.float64)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        e_total = int(cnt.item())
+    else:
+        e_total = e_local
+    ms_per_step = elapsed / args.steps * 1e3
+    value = e_total * L / (elapsed / args.steps)
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (the fused edge block), from HIP events in the timed region ----
+        calls, total_ms = per_op["edge_block"]
+        edge_ms = total_ms / calls
+        sz_w = 2 if args.edge_precision == "bf16" else 4
+        # algorithmic HBM bytes per launch: edge latents read once + written once, src/dst indices, and the
+        # per-node Ps/Pd tables read once (gather re-reads are cache traffic, not algorithmic bytes)
+        alg_bytes = 2 * e_local * d * 4 + 2 * e_local * 4 + 2 * n_local * h * 4
+        achieved = alg_bytes / (edge_ms * 1e-3) / 1e9
+        flops_exec = 2.0 * e_local * (d * h + (args.hidden_layers - 1) * h * h + h * d)
+        flops_alg = 2.0 * e_local * (3 * d * h + (args.hidden_layers - 1) * h * h + h * d)
+        mfma_peak = MFMA_BF16_PEAK_TFLOPS if args.edge_precision == "bf16" else MFMA_F32_PEAK_TFLOPS
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.isfile(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"edge_block:{n_local}:{k}:{d}:{args.edge_precision}")
+            except Exception:
+                traffic = None
+        roofline = {"kernel": "edge_block_kernel", "bound": "hbm", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "avg_launch_ms": round(edge_ms, 4), "launches": calls,
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "mfma": {"executed_tflops": round(flops_exec / (edge_ms * 1e-3) / 1e12, 1),
+                             "algorithmic_tflops": round(flops_alg / (edge_ms * 1e-3) / 1e12, 1),
+                             "peak_tflops": mfma_peak,
+                             "frac_executed": round(flops_exec / (edge_ms * 1e-3) / 1e12 / mfma_peak, 4),
+                             "frac_algorithmic": round(flops_alg / (edge_ms * 1e-3) / 1e12 / mfma_peak, 4)}}
+        kernels = {name: {"calls": c, "avg_ms": round(ms / c, 4)} for name, (c, ms) in sorted(per_op.items())}
+        if "aggregate" in per_op:
+            c, ms = per_op["aggregate"]
+            agg_bytes = e_local * d * 4 + e_local * 4 + n_local * d * 4
+            kernels["aggregate"]["algorithmic_GBps"] = round(agg_bytes / (ms / c * 1e-3) / 1e9, 1)
+            kernels["aggregate"]["hbm_frac"] = round(agg_bytes / (ms / c * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args)
+        line = {
+            "metric": "particle-edge updates/sec (E x MP-steps)", "value": value, "unit": "edge-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.edge_precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"{args.particles} particles/GPU uniform periodic box, k={k}, latent={d}, "
+                                   f"hidden={h}, {L} MP rounds, edge MLP {args.edge_precision} (f32 accumulate, f32 "
+                                   f"latents/LayerNorm/residual), node path {args.node_precision}, "
+                                   f"message_source={args.message_source}",
+                       "particles_per_gpu": args.particles, "edges_per_gpu": e_local, "k": k, "latent": d,
+                       "mp_steps": L, "parallelism": "single GPU" if world == 1 else f"{world} spatial tiles + halo"},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "graph_build": {"knn_ms": round(knn_ms, 3), "preprocess_total_s": round(t_build, 3)},
+        }
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

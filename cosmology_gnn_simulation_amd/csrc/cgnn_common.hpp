@@ -38,7 +38,32 @@ namespace cgnn {
 
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
-int grid_for_tiles(int64_t tiles_of_32_rows);
+int grid_for_tiles(int64_t tiles_of_32_rows, int blocks_per_cu = 2);
+
+// Persistent tile loop, XCD aware.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2),
+// so XCD x = blockIdx % 8 sweeps the contiguous x-th eighth of the tile range and its workgroups advance
+// through it together: rows gathered by neighbouring tiles (spatially sorted particles) are then fetched
+// once per L2.  Placement only affects speed, never results.
+struct TileRange {
+    int64_t first, end, stride;
+};
+__device__ __forceinline__ TileRange tile_range(int64_t tiles) {
+    const int wave = threadIdx.x >> 6;
+    const int nb = gridDim.x, b = blockIdx.x;
+    TileRange r;
+    if ((nb & 7) == 0) {
+        const int xcd = b & 7, slot = b >> 3, per = nb >> 3;
+        const int64_t t0 = tiles * xcd / 8;
+        r.first = t0 + (int64_t)slot * CGNN_WAVES_PER_BLOCK + wave;
+        r.end = tiles * (xcd + 1) / 8;
+        r.stride = (int64_t)per * CGNN_WAVES_PER_BLOCK;
+    } else {
+        r.first = (int64_t)b * CGNN_WAVES_PER_BLOCK + wave;
+        r.end = tiles;
+        r.stride = (int64_t)nb * CGNN_WAVES_PER_BLOCK;
+    }
+    return r;
+}
 
 __device__ __forceinline__ int feat_of(int t, int h, int i) { return 32 * t + 8 * (i >> 2) + 4 * h + (i & 3); }
 

@@ -22,11 +22,10 @@ __global__ __launch_bounds__(CGNN_BLOCK) void edge_block_kernel(MlpDev m, const 
                                                                 int residual) {
     if (WLDS) stage_weights_to_lds(m, 0);
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int wave = threadIdx.x >> 6;
     const int64_t tiles = (num_edges + 31) / 32;
     constexpr int D = 32 * DT, H = 32 * HT;
-    for (int64_t tile = (int64_t)blockIdx.x * CGNN_WAVES_PER_BLOCK + wave; tile < tiles;
-         tile += (int64_t)gridDim.x * CGNN_WAVES_PER_BLOCK) {
+    const TileRange tr = tile_range(tiles);
+    for (int64_t tile = tr.first; tile < tr.end; tile += tr.stride) {
         const int64_t e = tile * 32 + r;
         const int64_t ec = e < num_edges ? e : num_edges - 1;
         const int64_t s = src[ec], d = dst[ec];
@@ -67,7 +66,7 @@ static int launch_edge(const MlpDev& m, size_t lds, const float* ps, const float
                            "hipFuncSetAttribute(edge_block)");
         if (rc != CGNN_OK) return rc;
     }
-    const int grid = grid_for_tiles((num_edges + 31) / 32);
+    const int grid = grid_for_tiles((num_edges + 31) / 32, WLDS ? 1 : 2);
     kern<<<grid, CGNN_BLOCK, WLDS ? lds : 0, st>>>(m, ps, pd, src, dst, num_edges, e_in, e_out, e_upd, residual);
     return check_hip(hipGetLastError(), "cgnn_edge_block launch");
 }

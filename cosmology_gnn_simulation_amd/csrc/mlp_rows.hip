@@ -12,13 +12,12 @@ __global__ __launch_bounds__(CGNN_BLOCK) void mlp_rows_kernel(MlpDev m, const fl
                                                               int ld_x, float* __restrict__ y, int ld_y) {
     if (WLDS) stage_weights_to_lds(m, 0);
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int wave = threadIdx.x >> 6;
     const int64_t tiles = (n + 31) / 32;
     const int in_dim = m.in_dim[0], out_dim = m.out_dim[m.nh];
     const bool in_full = (in_dim == 32 * K0T) && (ld_x % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     const bool out_full = (out_dim == 32 * OT) && (ld_y % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-    for (int64_t tile = (int64_t)blockIdx.x * CGNN_WAVES_PER_BLOCK + wave; tile < tiles;
-         tile += (int64_t)gridDim.x * CGNN_WAVES_PER_BLOCK) {
+    const TileRange tr = tile_range(tiles);
+    for (int64_t tile = tr.first; tile < tr.end; tile += tr.stride) {
         const int64_t row = tile * 32 + r;
         const int64_t rowc = row < n ? row : n - 1;
         Operand<PREC, K0T> op0;
@@ -54,12 +53,11 @@ __global__ __launch_bounds__(CGNN_BLOCK) void project_kernel(const void* ws, con
                                                              int hidden, const float* __restrict__ x, int64_t n,
                                                              float* __restrict__ ps, float* __restrict__ pd) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int wave = threadIdx.x >> 6;
     const int64_t tiles = (n + 31) / 32;
     constexpr unsigned wbytes = DT * HT * 1024 * (PREC == CGNN_BF16 ? 2 : 4);
     const BufW<PREC> wsrc_s(ws, wbytes), wsrc_d(wd, wbytes);
-    for (int64_t tile = (int64_t)blockIdx.x * CGNN_WAVES_PER_BLOCK + wave; tile < tiles;
-         tile += (int64_t)gridDim.x * CGNN_WAVES_PER_BLOCK) {
+    const TileRange tr = tile_range(tiles);
+    for (int64_t tile = tr.first; tile < tr.end; tile += tr.stride) {
         const int64_t row = tile * 32 + r;
         const int64_t rowc = row < n ? row : n - 1;
         Operand<PREC, DT> op;
@@ -93,7 +91,7 @@ static int launch_mlp_rows(const MlpDev& m, size_t lds, const float* x, int64_t 
                            "hipFuncSetAttribute(mlp_rows)");
         if (rc != CGNN_OK) return rc;
     }
-    int grid = grid_for_tiles((n + 31) / 32);
+    int grid = grid_for_tiles((n + 31) / 32, WLDS ? 1 : 2);
     kern<<<grid, CGNN_BLOCK, WLDS ? lds : 0, st>>>(m, x, n, ld_x, y, ld_y);
     return check_hip(hipGetLastError(), "cgnn_mlp_rows launch");
 }

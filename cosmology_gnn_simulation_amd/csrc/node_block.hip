@@ -16,13 +16,12 @@ __global__ __launch_bounds__(CGNN_BLOCK) void node_block_kernel(MlpDev m, const 
                                                                 const float* __restrict__ agg, int64_t n,
                                                                 float* x_out, int residual) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const int wave = threadIdx.x >> 6;
     const int64_t tiles = (n + 31) / 32;
     constexpr int D = 32 * DT, H = 32 * HT;
     constexpr unsigned wbytes = DT * HT * 1024 * (PREC == CGNN_BF16 ? 2 : 4);
     const BufW<PREC> wsrc_x(wx, wbytes), wsrc_a(wa, wbytes);
-    for (int64_t tile = (int64_t)blockIdx.x * CGNN_WAVES_PER_BLOCK + wave; tile < tiles;
-         tile += (int64_t)gridDim.x * CGNN_WAVES_PER_BLOCK) {
+    const TileRange tr = tile_range(tiles);
+    for (int64_t tile = tr.first; tile < tr.end; tile += tr.stride) {
         const int64_t row = tile * 32 + r;
         const int64_t rowc = row < n ? row : n - 1;
         f32x16 xv[DT];

@@ -36,11 +36,12 @@ static int num_cus() {
 }
 
 // One wave owns one 32-row tile at a time; blocks are persistent (grid-stride).
-int grid_for_tiles(int64_t tiles) {
+int grid_for_tiles(int64_t tiles, int blocks_per_cu) {
     int64_t blocks = (tiles + CGNN_WAVES_PER_BLOCK - 1) / CGNN_WAVES_PER_BLOCK;
-    const int64_t cap = (int64_t)num_cus() * 2;
+    const int64_t cap = (int64_t)num_cus() * blocks_per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
+    if (blocks >= 8) blocks = (blocks + 7) & ~(int64_t)7;   // multiple of 8: enables the XCD-aware tile map
     return (int)blocks;
 }
 

@@ -146,7 +146,8 @@ def preprocess(position_seq, temperature_seq, metadata, target_position=None, ta
     node_features = torch.cat((nvel.reshape(nvel.size(0), -1), ntmp.reshape(ntmp.size(0), -1)), dim=-1)
 
     # --- periodic k-NN graph + edge features on the device ---
-    edge_index, edge_attr, senders, _ = knn_graph_periodic(recent_position, box_size, int(num_neighbors))
+    edge_index, edge_attr, senders, order = knn_graph_periodic(recent_position, box_size, int(num_neighbors),
+                                                                want_order=True)
     n = recent_position.shape[0]
     assert int(senders.max()) < n, f"Max sender index {int(senders.max())} >= {n}"
 
@@ -186,4 +187,5 @@ def preprocess(position_seq, temperature_seq, metadata, target_position=None, ta
         box_size=torch.tensor([box_size], dtype=torch.float32, device=device),
     )
     graph._cgnn_fixed_k = int(num_neighbors)
+    graph._cgnn_order = order          # spatial (cell-sorted) particle order: a locality hint for the engine
     return graph

@@ -94,4 +94,11 @@ class Batch(Data):
         ks = {getattr(g, "_cgnn_fixed_k", None) for g in graphs}
         if len(ks) == 1 and None not in ks:
             out._cgnn_fixed_k = ks.pop()
+        orders = [getattr(g, "_cgnn_order", None) for g in graphs]
+        if all(o is not None for o in orders):
+            out._cgnn_order = torch.cat([o + off for o, off in zip(orders, offsets)])
         return out
+
+    def to(self, device, non_blocking: bool = False) -> "Batch":
+        super().to(device, non_blocking)
+        return self

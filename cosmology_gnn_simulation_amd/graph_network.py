@@ -137,6 +137,31 @@ def _graph_arrays(data, num_nodes: int):
     return src, dst, fixed_k
 
 
+def _locality_plan(data, n: int, k: int, src: torch.Tensor):
+    """Renumber the particles in the spatial (cell-sorted) order the k-NN build produced, so that a receiver's
+    senders sit in nearby rows and the per-edge gathers hit L2 instead of HBM.  Returns ``(order, inverse,
+    src_sorted, dst_sorted)`` or ``None`` when the graph carries no order hint.  Index bookkeeping only (torch
+    indexing, once per graph, cached on the data object); the per-forward row permutations run in HIP."""
+    order = getattr(data, "_cgnn_order", None)
+    if order is None or k <= 0 or order.numel() != n:
+        return None
+    cached = getattr(data, "_cgnn_plan", None)
+    if cached is not None and cached[0] is src:
+        return cached[1]
+    order = order.to(torch.int32)
+    ol = order.long()
+    inv = torch.empty(n, dtype=torch.int32, device=order.device)
+    inv[ol] = torch.arange(n, dtype=torch.int32, device=order.device)
+    src_sorted = inv[src.view(n, k)[ol].reshape(-1).long()].contiguous()
+    dst_sorted = torch.arange(n, dtype=torch.int32, device=order.device).repeat_interleave(k)
+    plan = (order, inv, src_sorted, dst_sorted)
+    try:
+        data._cgnn_plan = (src, plan)
+    except Exception:
+        pass
+    return plan
+
+
 # ----------------------------------------------------------------------------
 # modules
 # ----------------------------------------------------------------------------
@@ -304,6 +329,7 @@ class EncodeProcessDecode(nn.Module):
         self.message_source = "x_j"
         self.node_precision = "fp32"
         self.edge_precision = "fp32"
+        self.locality_sort = True     # run in the k-NN build's spatial order when the graph carries it
         self._packed = None
 
     # -- packing ---------------------------------------------------------------
@@ -361,6 +387,11 @@ class EncodeProcessDecode(nn.Module):
             edge_attr = edge_attr.float().contiguous()
             n = x.shape[0]
             src, dst, fixed_k = _graph_arrays(g, n)
+            plan = _locality_plan(g, n, fixed_k, src) if (self.locality_sort and fixed_k > 0) else None
+            if plan is not None:
+                order, inv, src, dst = plan
+                x = ops.gather_rows(x, order)
+                edge_attr = ops.gather_rows(edge_attr.view(n, -1), order).view(n * fixed_k, -1)
             P = self._pack(x.shape[1], edge_attr.shape[1])
             xl = ops.mlp_rows(P["enc_node"], x)
             el = ops.mlp_rows(P["enc_edge"], edge_attr)
@@ -380,4 +411,10 @@ class EncodeProcessDecode(nn.Module):
             out = {"acceleration": ops.mlp_rows(P["dec_acc"], xl), "temp_rate": ops.mlp_rows(P["dec_tr"], xl)}
             if want_latents:
                 out["x_latent"], out["edge_latent"] = xl, el
+            if plan is not None:   # back to the caller's particle numbering
+                out["acceleration"] = ops.gather_rows(out["acceleration"], inv)
+                out["temp_rate"] = ops.gather_rows(out["temp_rate"], inv)
+                if want_latents:
+                    out["x_latent"] = ops.gather_rows(xl, inv)
+                    out["edge_latent"] = ops.gather_rows(el.view(n, -1), inv).view(n * fixed_k, -1)
         return out

@@ -15,6 +15,49 @@ from . import _lib
 from ._lib import BF16, F32, CgnnError, Linear, Mlp, check, f32c, i32c, ptr, require_device, stream_ptr
 
 
+# ---- optional per-op timing with HIP events on the launch stream (bench.py) -------------------------------
+_timer = None
+
+
+class OpTimer:
+    """``with OpTimer() as t: ...; t.summary()`` -> {op: (calls, total_ms)}.  Events are recorded on the stream
+    the kernels are launched on (torch's current stream), so no extra synchronisation enters the region."""
+
+    def __init__(self):
+        self.records = {}
+
+    def __enter__(self):
+        global _timer
+        _timer = self
+        return self
+
+    def __exit__(self, *exc):
+        global _timer
+        _timer = None
+        return False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.records.items()}
+
+
+class _timed:
+    def __init__(self, name: str, device):
+        self.name, self.device = name, device
+
+    def __enter__(self):
+        if _timer is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream(self.device))
+
+    def __exit__(self, *exc):
+        if _timer is not None:
+            self.b.record(torch.cuda.current_stream(self.device))
+            _timer.records.setdefault(self.name, []).append((self.a, self.b))
+        return False
+
+
 def _prec(p) -> int:
     if isinstance(p, int):
         return p
@@ -88,7 +131,8 @@ def mlp_rows(mlp: PackedMLP, x: torch.Tensor, out: Optional[torch.Tensor] = None
     if x.dim() != 2 or x.shape[1] != mlp.in_dim:
         raise CgnnError(f"mlp_rows: input is {tuple(x.shape)}, the MLP expects [n, {mlp.in_dim}]")
     y = out if out is not None else torch.empty((n, mlp.out_dim), dtype=torch.float32, device=x.device)
-    check(_lib.load().cgnn_mlp_rows(C.byref(mlp.struct()), x.data_ptr(), n, x.stride(0), y.data_ptr(), y.stride(0),
+    with _timed("mlp_rows", x.device):
+        check(_lib.load().cgnn_mlp_rows(C.byref(mlp.struct()), x.data_ptr(), n, x.stride(0), y.data_ptr(), y.stride(0),
                                     stream_ptr(x.device)), "cgnn_mlp_rows")
     return y
 
@@ -104,7 +148,8 @@ def project_nodes(ws: Optional[PackedLinear], wd: Optional[PackedLinear], x: tor
         pd = torch.empty((n, wd.out_dim), dtype=torch.float32, device=x.device)
     s1 = ws.struct() if ws is not None else None
     s2 = wd.struct() if wd is not None else None
-    check(_lib.load().cgnn_project_nodes(C.byref(s1) if s1 is not None else None,
+    with _timed("project_nodes", x.device):
+        check(_lib.load().cgnn_project_nodes(C.byref(s1) if s1 is not None else None,
                                          C.byref(s2) if s2 is not None else None, ref.precision, x.data_ptr(), n,
                                          ptr(ps) if ws is not None else None, ptr(pd) if wd is not None else None,
                                          stream_ptr(x.device)), "cgnn_project_nodes")
@@ -125,7 +170,8 @@ def edge_block(mlp: PackedMLP, ps: torch.Tensor, pd: torch.Tensor, src: torch.Te
             raise CgnnError(f"edge_block: {name} must be contiguous float32")
     if src.numel() != ne or dst.numel() != ne:
         raise CgnnError("edge_block: src/dst length does not match the edge latents")
-    check(_lib.load().cgnn_edge_block(C.byref(mlp.struct()), ps.data_ptr(), pd.data_ptr(), src.data_ptr(),
+    with _timed("edge_block", e_in.device):
+        check(_lib.load().cgnn_edge_block(C.byref(mlp.struct()), ps.data_ptr(), pd.data_ptr(), src.data_ptr(),
                                       dst.data_ptr(), ne, e_in.data_ptr(), e_out.data_ptr(), ptr(e_upd),
                                       1 if residual else 0, latent, stream_ptr(e_in.device)), "cgnn_edge_block")
     return e_out
@@ -143,7 +189,8 @@ def aggregate(table: torch.Tensor, gather: Optional[torch.Tensor], dst: Optional
         num_edges = gather.numel() if gather is not None else (dst.numel() if dst is not None else table.shape[0])
     if out is None:
         out = torch.empty((num_nodes, width), dtype=torch.float32, device=table.device)
-    check(_lib.load().cgnn_aggregate(table.data_ptr(), ptr(gather), ptr(dst), num_edges, fixed_k, num_nodes, width,
+    with _timed("aggregate", table.device):
+        check(_lib.load().cgnn_aggregate(table.data_ptr(), ptr(gather), ptr(dst), num_edges, fixed_k, num_nodes, width,
                                      out.data_ptr(), stream_ptr(table.device)), "cgnn_aggregate")
     return out
 
@@ -155,7 +202,8 @@ def node_block(mlp: PackedMLP, w_x: PackedLinear, w_agg: PackedLinear, x: torch.
     if x_out is None:
         x_out = torch.empty_like(x)
     sx, sa = w_x.struct(), w_agg.struct()
-    check(_lib.load().cgnn_node_block(C.byref(mlp.struct()), C.byref(sx), C.byref(sa), x.data_ptr(), agg.data_ptr(),
+    with _timed("node_block", x.device):
+        check(_lib.load().cgnn_node_block(C.byref(mlp.struct()), C.byref(sx), C.byref(sa), x.data_ptr(), agg.data_ptr(),
                                       n, x_out.data_ptr(), 1 if residual else 0, latent, stream_ptr(x.device)),
           "cgnn_node_block")
     return x_out
@@ -179,7 +227,8 @@ def knn_periodic(pos: torch.Tensor, box_size: float, k: int, query_ids: Optional
     senders = torch.empty(nq * k, dtype=torch.int32, device=pos.device)
     edge_attr = torch.empty((nq * k, 4), dtype=torch.float32, device=pos.device) if want_edge_attr else None
     st = stream_ptr(pos.device)
-    check(lib.cgnn_knn_periodic(pos.data_ptr(), n, float(box_size), k, ptr(query_ids), nq, senders.data_ptr(),
+    with _timed("knn_periodic", pos.device):
+        check(lib.cgnn_knn_periodic(pos.data_ptr(), n, float(box_size), k, ptr(query_ids), nq, senders.data_ptr(),
                                 ptr(edge_attr), ws.data_ptr(), ws_bytes, st), "cgnn_knn_periodic")
     order = None
     if want_order:

@@ -272,10 +272,27 @@ def test_random_init_matches_reference_rng_order():
     meta = synthetic.make_metadata()
     d = data_utils.preprocess(snap["Coordinates"][:W], snap["InternalEnergy"][:W], meta, None, None, 0.0, 8, 0.01, 1.0)
     torch.manual_seed(123)
-    m = graph_network.EncodeProcessDecode(32, 32, 2, 2, 3)
-    m.requires_grad_(False)
-    m = m.to(DEV)
-    out = m(d)
+    m = graph_network.EncodeProcessDecode(32, 32, 2, 2, 3).to(DEV)
+    with torch.no_grad():
+        out = m(d)
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
     want = cpu_ref.encode_process_decode(sd, d.x.cpu(), d.edge_index.cpu(), d.edge_attr.cpu(), 2, 2)
     assert rel_err(out["acceleration"].cpu(), want["acceleration"]) <= TOL
+
+
+def test_locality_sorted_execution_is_bitwise_equivalent():
+    """The engine renumbers particles in the k-NN build's spatial order (L2 locality); per-receiver summation
+    order is unchanged, so the results must be bit-identical to the unsorted run."""
+    snap = synthetic.make_snapshot(5000, seed=31)
+    meta = synthetic.make_metadata()
+    d = data_utils.preprocess(snap["Coordinates"][:W], snap["InternalEnergy"][:W], meta, None, None, 0.0, 16, 0.01, 1.0)
+    assert sorted(d._cgnn_order.cpu().tolist()) == list(range(5000))
+    m = graph_network.EncodeProcessDecode(64, 64, 2, 2, 3)
+    m.load_state_dict(synthetic.make_state_dict(64, 64, 2, 2, 3))
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        a = m.forward_with_latents(d)
+        m.locality_sort = False
+        b = m.forward_with_latents(d)
+    for key in ("acceleration", "temp_rate", "x_latent", "edge_latent"):
+        assert torch.equal(a[key], b[key]), key
