@@ -1,0 +1,274 @@
+"""Multi-GPU message passing: spatial tiles + one-hop halo exchange of node latents.
+
+The reference is single-process; this is new design for one
+node of 8 MI355X.  The periodic box is cut into ``world`` spatial tiles, one per rank
+(one process per GPU).  An edge belongs to its receiver's rank, so edge latents never
+move; what a round needs from other ranks is the latent row ``x[src]`` of every
+sender that lives elsewhere (a *ghost*).  Per round:
+
+    pack owned rows peers asked for  ->  all-to-all-v over RCCL/xGMI  ->  ghost rows
+
+``torch.distributed.all_to_all_single`` with split sizes is exactly the grouped
+send/recv this needs: in a 2x2x2 periodic tiling every rank neighbours all 7 others,
+one peer per xGMI link, so all links carry traffic at once and nothing is ring-bound.
+The receive buffer *is* the ghost block of the local latent table (ghosts are stored
+grouped by owner rank), so there is no unpack pass.
+
+Index bookkeeping (ownership, ghost lists, global->local maps) is host logic done once
+per graph with torch indexing; the per-round data path is HIP kernels + RCCL.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops, synthetic
+
+
+# ----------------------------------------------------------------------------
+# tiling
+# ----------------------------------------------------------------------------
+
+def tile_grid(world: int) -> Tuple[int, int, int]:
+    """Near-cubic factorisation: 1->(1,1,1) 2->(2,1,1) 4->(2,2,1) 8->(2,2,2) ..."""
+    dims = [1, 1, 1]
+    n, p = world, 2
+    factors = []
+    while n > 1:
+        while n % p == 0:
+            factors.append(p)
+            n //= p
+        p += 1
+    for f in sorted(factors, reverse=True):
+        dims[dims.index(min(dims))] *= f
+    return tuple(sorted(dims, reverse=True))
+
+
+def owner_of(pos: torch.Tensor, box_size: float, world: int) -> torch.Tensor:
+    """Rank owning each particle: the tile of the periodic box that contains it."""
+    px, py, pz = tile_grid(world)
+    g = torch.tensor([px, py, pz], device=pos.device, dtype=torch.float32)
+    cell = torch.floor(pos / box_size * g).to(torch.int64)
+    cell = torch.minimum(cell.clamp_min_(0), (g - 1).to(torch.int64))
+    return ((cell[:, 0] * py + cell[:, 1]) * pz + cell[:, 2]).to(torch.int32)
+
+
+# ----------------------------------------------------------------------------
+# shard description
+# ----------------------------------------------------------------------------
+
+@dataclass
+class Shard:
+    rank: int
+    world: int
+    k: int
+    n_owned: int
+    n_ghost: int
+    owned_global: torch.Tensor        # int64 [n_owned]  global ids, in the local (spatial) order
+    ghost_global: torch.Tensor        # int64 [n_ghost]  grouped by owner rank
+    src_local: torch.Tensor           # int32 [n_owned*k] rows of the local table [owned | ghosts]
+    dst_local: torch.Tensor           # int32 [n_owned*k]
+    edge_attr: torch.Tensor           # [n_owned*k, 4]
+    recv_counts: List[int]            # ghost rows coming from each rank
+    want_global: List[torch.Tensor] = field(default_factory=list)   # ids requested from each rank
+    send_idx: Optional[torch.Tensor] = None    # int32 local owned rows to pack, grouped by destination
+    send_counts: Optional[List[int]] = None
+    x_feat: Optional[torch.Tensor] = None      # [n_owned, F] encoder inputs of the owned particles
+    knn_ms: float = 0.0
+
+    @property
+    def n_local(self) -> int:
+        return self.n_owned + self.n_ghost
+
+
+def build_shard(pos_global: torch.Tensor, box_size: float, k: int, world: int, rank: int,
+                knn_fn: Optional[Callable] = None) -> Shard:
+    """Everything rank ``rank`` can derive locally from the global positions: its owned set, their k-NN
+    senders, the ghost set and the global->local renumbering.  ``knn_fn(pos, box, k, query_ids)`` defaults to
+    the HIP k-NN; it returns ``(senders int32 [nq*k], edge_attr [nq*k, 4], order)``."""
+    dev = pos_global.device
+    n_total = pos_global.shape[0]
+    owner = owner_of(pos_global, box_size, world)
+    owned = torch.nonzero(owner == rank).squeeze(1)
+    knn = knn_fn or (lambda p, b, kk, q: ops.knn_periodic(p, b, kk, query_ids=q, want_edge_attr=True,
+                                                          want_order=True))
+    t0 = time.perf_counter()
+    # a one-query pass builds the cell grid and yields the spatial (cell-sorted) order, so that the local
+    # numbering is cache friendly; then the real pass over the owned queries in that order
+    if owned.numel():
+        _, _, order = knn(pos_global, box_size, k, owned[:1].to(torch.int32))
+        if order is not None:
+            order = order.long()
+            owned = order[owner[order] == rank]
+    senders, edge_attr, _ = knn(pos_global, box_size, k, owned.to(torch.int32))
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    knn_ms = (time.perf_counter() - t0) * 1e3
+    n_owned = owned.numel()
+    senders = senders.long()
+    remote = owner[senders] != rank
+    ghosts = torch.unique(senders[remote])
+    g_owner = owner[ghosts].long()
+    perm = torch.argsort(g_owner * n_total + ghosts)      # group by owner rank, ascending id inside
+    ghosts = ghosts[perm]
+    g_owner = g_owner[perm]
+    recv_counts = torch.bincount(g_owner, minlength=world).tolist()
+    g2l = torch.full((n_total,), -1, dtype=torch.int32, device=dev)
+    g2l[owned] = torch.arange(n_owned, dtype=torch.int32, device=dev)
+    g2l[ghosts] = n_owned + torch.arange(ghosts.numel(), dtype=torch.int32, device=dev)
+    src_local = g2l[senders].contiguous()
+    dst_local = torch.arange(n_owned, dtype=torch.int32, device=dev).repeat_interleave(k)
+    want = list(torch.split(ghosts, recv_counts))
+    sh = Shard(rank, world, k, n_owned, ghosts.numel(), owned, ghosts, src_local, dst_local, edge_attr,
+               recv_counts, want_global=want, knn_ms=knn_ms)
+    sh._g2l = g2l
+    return sh
+
+
+def finish_shard(sh: Shard, requests_from_peers: Sequence[torch.Tensor]) -> Shard:
+    """``requests_from_peers[r]`` = global ids rank r wants from us -> local rows to pack, grouped by r."""
+    idx = [sh._g2l[req.long()] for req in requests_from_peers]
+    for r, t in enumerate(idx):
+        if t.numel() and (int(t.min()) < 0 or int(t.max()) >= sh.n_owned):
+            raise RuntimeError(f"rank {sh.rank}: rank {r} requested rows this rank does not own")
+    sh.send_counts = [int(t.numel()) for t in idx]
+    sh.send_idx = torch.cat(idx).to(torch.int32).contiguous() if idx else torch.empty(0, dtype=torch.int32)
+    return sh
+
+
+def exchange_requests(sh: Shard, group=None) -> Shard:
+    """Setup-time all-to-all of the ghost id lists (sizes, then ids)."""
+    import torch.distributed as dist
+    dev = sh.owned_global.device
+    counts_out = torch.tensor(sh.recv_counts, dtype=torch.int64, device=dev)
+    counts_in = torch.empty_like(counts_out)
+    dist.all_to_all_single(counts_in, counts_out, group=group)
+    counts_in_l = counts_in.tolist()
+    recv = torch.empty(int(sum(counts_in_l)), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(recv, sh.ghost_global.contiguous(), output_split_sizes=counts_in_l,
+                           input_split_sizes=sh.recv_counts, group=group)
+    return finish_shard(sh, list(torch.split(recv, counts_in_l)))
+
+
+# ----------------------------------------------------------------------------
+# halo exchange (per round)
+# ----------------------------------------------------------------------------
+
+class HaloExchange:
+    """Fills the ghost block ``table[n_owned:]`` from the owners' rows ``table[:n_owned]``."""
+
+    def __init__(self, sh: Shard, group=None, pack_fn: Optional[Callable] = None):
+        self.sh, self.group = sh, group
+        self.pack = pack_fn or (lambda table, idx, out: ops.gather_rows(table, idx, out))
+        self._buf = None
+
+    def __call__(self, table: torch.Tensor) -> None:
+        import torch.distributed as dist
+        sh = self.sh
+        width = table.shape[1]
+        if self._buf is None or self._buf.shape != (sh.send_idx.numel(), width) or self._buf.device != table.device:
+            self._buf = torch.empty((sh.send_idx.numel(), width), dtype=table.dtype, device=table.device)
+        if sh.send_idx.numel():
+            self.pack(table, sh.send_idx, self._buf)
+        ghosts = table[sh.n_owned:]
+        dist.all_to_all_single(ghosts, self._buf, output_split_sizes=sh.recv_counts,
+                               input_split_sizes=sh.send_counts, group=self.group)
+
+
+# ----------------------------------------------------------------------------
+# sharded forward
+# ----------------------------------------------------------------------------
+
+class ShardedForward:
+    """``EncodeProcessDecode.forward`` over one spatial tile.  ``halo(table)`` must fill the ghost rows of
+    ``table`` ([n_owned + n_ghost, D]) from their owners; by default it is the RCCL all-to-all above.
+    Returns the predictions of the owned particles (local order; ``shard.owned_global`` maps them back)."""
+
+    def __init__(self, model, shard: Shard, halo: Optional[Callable] = None):
+        self.model, self.sh = model, shard
+        self.halo = halo if halo is not None else HaloExchange(shard)
+        self._bufs = None
+
+    def _buffers(self, D: int, H: int, dev):
+        sh = self.sh
+        key = (D, H, dev)
+        if self._bufs is None or self._bufs[0] != key:
+            x_all = torch.empty((sh.n_local, D), dtype=torch.float32, device=dev)
+            ps = torch.empty((sh.n_local, H), dtype=torch.float32, device=dev)
+            pd = torch.empty((sh.n_owned, H), dtype=torch.float32, device=dev)
+            agg = torch.empty((sh.n_owned, D), dtype=torch.float32, device=dev)
+            self._bufs = (key, x_all, ps, pd, agg)
+        return self._bufs[1:]
+
+    # the pieces are separate methods so that a single-process test can interleave several shards
+    def encode(self):
+        m, sh = self.model, self.sh
+        P = m._pack(sh.x_feat.shape[1], sh.edge_attr.shape[1])
+        D = m._latent_size
+        H = P["rounds"][0].ws.out_dim if P["rounds"] else D
+        self.P = P
+        self.x_all, self.ps, self.pd, self.agg = self._buffers(D, H, sh.x_feat.device)
+        ops.mlp_rows(P["enc_node"], sh.x_feat, out=self.x_all[:sh.n_owned])
+        self.el = ops.mlp_rows(P["enc_edge"], sh.edge_attr)
+        self.e_upd = torch.empty_like(self.el) if m.message_source == "edge" else None
+
+    def round(self, i: int):
+        m, sh = self.model, self.sh
+        p = self.P["rounds"][i]
+        x_own = self.x_all[:sh.n_owned]
+        ops.project_nodes(p.ws, None, self.x_all, self.ps, None)        # senders may be ghosts
+        ops.project_nodes(None, p.wd, x_own, None, self.pd)             # receivers are owned
+        edge_mode = m.message_source == "edge"
+        ops.edge_block(p.edge, self.ps, self.pd, sh.src_local, sh.dst_local, self.el, self.el,
+                       self.e_upd if edge_mode else None, True)
+        if edge_mode:
+            ops.aggregate(self.e_upd, None, sh.dst_local, sh.n_owned, sh.k, sh.src_local.numel(), self.agg)
+        else:
+            ops.aggregate(self.x_all, sh.src_local, sh.dst_local, sh.n_owned, sh.k, sh.src_local.numel(), self.agg)
+        ops.node_block(p.node, p.wx, p.wa, x_own, self.agg, x_own, True)
+
+    def decode(self) -> dict:
+        x_own = self.x_all[:self.sh.n_owned]
+        return {"acceleration": ops.mlp_rows(self.P["dec_acc"], x_own),
+                "temp_rate": ops.mlp_rows(self.P["dec_tr"], x_own)}
+
+    def __call__(self) -> dict:
+        with torch.no_grad():
+            self.encode()
+            n_rounds = len(self.P["rounds"])
+            for i in range(n_rounds):
+                # x_j aggregation and the sender projections both read ghost latents of the current round
+                self.halo(self.x_all)
+                self.round(i)
+            return self.decode()
+
+
+# ----------------------------------------------------------------------------
+# synthetic shard for bench.py (every rank regenerates the same global box from the seed)
+# ----------------------------------------------------------------------------
+
+def build_synthetic_shard(particles_per_gpu: int, world: int, rank: int, k: int, seed: int, device, metadata: dict,
+                          group=None) -> Shard:
+    from .data_utils import preprocess  # noqa: F401  (feature arithmetic is shared with the single-GPU path)
+    n_total = particles_per_gpu * world
+    snap = synthetic.make_snapshot(n_total, seed=seed)
+    box, dt = metadata["box_size"], metadata["dt"]
+    coords = snap["Coordinates"][:5].to(device)                     # [W, N, 3]
+    energy = snap["InternalEnergy"][:5].to(device)
+    pos = torch.remainder(coords[-1], box).contiguous()
+    sh = build_shard(pos, box, k, world, rank)
+    sh = exchange_requests(sh, group)
+    own = sh.owned_global
+    # node features of the owned particles: same arithmetic as data_utils.preprocess (noise_std = 0)
+    pseq = torch.remainder(coords[:, own].permute(1, 0, 2), box)
+    d = pseq[:, 1:] - pseq[:, :-1]
+    half = box / 2
+    d = torch.where(d < -half, d + box, d)
+    d = torch.where(d > half, d - box, d)
+    vel = (d / dt - metadata["vel_mean"]) / metadata["vel_std"]
+    tmp = (energy[:, own].permute(1, 0, 2) - metadata["temp_mean"]) / metadata["temp_std"]
+    sh.x_feat = torch.cat((vel.reshape(vel.size(0), -1), tmp.reshape(tmp.size(0), -1)), dim=-1).float().contiguous()
+    return sh
