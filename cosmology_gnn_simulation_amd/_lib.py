@@ -24,8 +24,9 @@ EXPORTS = (
     "cgnn_version", "cgnn_arch", "cgnn_last_error", "cgnn_packed_linear_bytes", "cgnn_pack_linear",
     "cgnn_mlp_rows", "cgnn_project_nodes", "cgnn_edge_block", "cgnn_aggregate", "cgnn_node_block",
     "cgnn_knn_workspace_bytes", "cgnn_knn_periodic", "cgnn_knn_sorted_order", "cgnn_segment_colsum",
-    "cgnn_gather_rows", "cgnn_scatter_rows",
+    "cgnn_gather_rows", "cgnn_scatter_rows", "cgnn_tiled_rows", "cgnn_relayout",
 )
+ROWS, TILED32 = 0, 1
 
 
 class Linear(C.Structure):
@@ -63,10 +64,13 @@ def load() -> C.CDLL:
     lib.cgnn_packed_linear_bytes.restype = sz
     lib.cgnn_packed_linear_bytes.argtypes = [i32, i32, i32]
     lib.cgnn_pack_linear.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp]
-    lib.cgnn_mlp_rows.argtypes = [C.POINTER(Mlp), vp, i64, i32, vp, i32, vp]
+    lib.cgnn_mlp_rows.argtypes = [C.POINTER(Mlp), vp, i64, i32, vp, i32, i32, vp]
+    lib.cgnn_tiled_rows.restype = i64
+    lib.cgnn_tiled_rows.argtypes = [i64]
+    lib.cgnn_relayout.argtypes = [vp, i32, vp, i32, i64, i32, vp]
     lib.cgnn_project_nodes.argtypes = [C.POINTER(Linear), C.POINTER(Linear), i32, vp, i64, vp, vp, vp]
     lib.cgnn_edge_block.argtypes = [C.POINTER(Mlp), vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, vp]
-    lib.cgnn_aggregate.argtypes = [vp, vp, vp, i64, i32, i64, i32, vp, vp]
+    lib.cgnn_aggregate.argtypes = [vp, i32, vp, vp, i64, i32, i64, i32, vp, vp]
     lib.cgnn_node_block.argtypes = [C.POINTER(Mlp), C.POINTER(Linear), C.POINTER(Linear), vp, vp, i64, vp, i32, i32, vp]
     lib.cgnn_knn_workspace_bytes.restype = sz
     lib.cgnn_knn_workspace_bytes.argtypes = [i64, i32]

@@ -38,7 +38,7 @@ namespace cgnn {
 
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
-int grid_for_tiles(int64_t tiles_of_32_rows, int blocks_per_cu = 2);
+int grid_for_tiles(int64_t tiles_of_32_rows, int blocks_per_cu = 2, int waves_per_block = CGNN_WAVES_PER_BLOCK);
 
 // Persistent tile loop, XCD aware.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2),
 // so XCD x = blockIdx % 8 sweeps the contiguous x-th eighth of the tile range and its workgroups advance
@@ -48,19 +48,22 @@ struct TileRange {
     int64_t first, end, stride;
 };
 __device__ __forceinline__ TileRange tile_range(int64_t tiles) {
-    const int wave = threadIdx.x >> 6;
+    // the wave index is wave-uniform; telling the compiler so keeps the whole tile loop (64-bit tile index,
+    // tile base pointers) in scalar registers
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int waves = blockDim.x >> 6;
     const int nb = gridDim.x, b = blockIdx.x;
     TileRange r;
     if ((nb & 7) == 0) {
         const int xcd = b & 7, slot = b >> 3, per = nb >> 3;
         const int64_t t0 = tiles * xcd / 8;
-        r.first = t0 + (int64_t)slot * CGNN_WAVES_PER_BLOCK + wave;
+        r.first = t0 + (int64_t)slot * waves + wave;
         r.end = tiles * (xcd + 1) / 8;
-        r.stride = (int64_t)per * CGNN_WAVES_PER_BLOCK;
+        r.stride = (int64_t)per * waves;
     } else {
-        r.first = (int64_t)b * CGNN_WAVES_PER_BLOCK + wave;
+        r.first = (int64_t)b * waves + wave;
         r.end = tiles;
-        r.stride = (int64_t)nb * CGNN_WAVES_PER_BLOCK;
+        r.stride = (int64_t)nb * waves;
     }
     return r;
 }
@@ -121,7 +124,7 @@ template <>
 struct Frag<CGNN_BF16> {
     typedef bf16x8 type;
     static constexpr int S = 2;
-    static constexpr int GS = 8;
+    static constexpr int GS = 4;
 };
 
 template <int KT>
@@ -195,15 +198,26 @@ __device__ __forceinline__ void dense(f32x16 (&out)[OT], const Operand<PREC, KT>
 // ---------------------------------------------------------------------------
 // act-layout tile helpers (T tiles of 32 features, one row per lane pair)
 // ---------------------------------------------------------------------------
-template <int T>
-__device__ __forceinline__ void acc_fill_bias(f32x16 (&acc)[T], const float* __restrict__ b, int out_dim, int h) {
+template <typename P>
+struct VecOf4;
+template <>
+struct VecOf4<const float*> {
+    typedef const f32x4* type;
+};
+template <>
+struct VecOf4<const __attribute__((address_space(3))) float*> {
+    typedef const __attribute__((address_space(3))) f32x4* type;
+};
+
+template <int T, typename P>
+__device__ __forceinline__ void acc_fill_bias(f32x16 (&acc)[T], P b, int out_dim, int h) {
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int f = 32 * t + 8 * g + 4 * h;
             if (b != nullptr && f + 3 < out_dim) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(b + f);
+                const f32x4 v = *(typename VecOf4<P>::type)(b + f);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[t][4 * g + c] = v[c];
             } else {
@@ -251,6 +265,107 @@ __device__ __forceinline__ void store_rows_full(const f32x16 (&a)[T], float* __r
         }
 }
 
+// TILED32 layout (cgnn_layout in cgnn.h) of an [n, 32 T] float matrix: whole 32-row tiles, each stored in act
+// order, so that a wave moves its tile with 4 T fully coalesced 1-KiB instructions (lane-linear 16 B):
+//   element (row 32*tile + r, feature 32t + 8g + 4h + c)  at  tile*(1024 T) + ((4t + g)*64 + 32h + r)*4 + c
+// Row-per-lane access to a row-major matrix costs ~3x (loads) to ~7x (stores) more texture-addresser cycles
+// per instruction (32 partial lines instead of 8 full ones), which made the edge kernel address-bound.
+template <int T>
+__device__ __forceinline__ void load_tile(f32x16 (&a)[T], const float* __restrict__ tile_base, int lane) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tile_base + ((4 * t + g) * 64 + lane) * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[t][4 * g + c] = v[c];
+        }
+}
+
+template <int T>
+__device__ __forceinline__ void add_tile(f32x16 (&a)[T], const float* __restrict__ tile_base, int lane) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tile_base + ((4 * t + g) * 64 + lane) * 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[t][4 * g + c] += v[c];
+        }
+}
+
+template <int T>
+__device__ __forceinline__ void store_tile(const f32x16 (&a)[T], float* __restrict__ tile_base, int lane) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = a[t][4 * g + c];
+            *reinterpret_cast<f32x4*>(tile_base + ((4 * t + g) * 64 + lane) * 4) = v;
+        }
+}
+
+// Per-node projection rows ("P rows": Ps = x Ws^T, Pd = x Wd^T + b1) as the edge kernel gathers them.
+//  f32 precision : plain row-major f32 [n, H].
+//  bf16 precision: bf16, H values per row stored half-split, [h][t][g][c]: lane (r, h) owns one contiguous
+//                  run of H/2 bf16 (16 HT bytes * 2), read with HT*2 16-byte loads.  Halves the gather bytes
+//                  and the table footprint (better L2 residency) at the precision the bf16 MLP has anyway.
+template <int PREC>
+struct PRow;
+template <>
+struct PRow<CGNN_F32> {
+    typedef float elem;
+    template <int HT>
+    static __device__ __forceinline__ void load(f32x16 (&acc)[HT], const float* __restrict__ base, int64_t row, int h) {
+        load_rows_full<HT>(acc, base + row * (32 * HT), h);
+    }
+    template <int HT>
+    static __device__ __forceinline__ void add(f32x16 (&acc)[HT], const float* __restrict__ base, int64_t row, int h) {
+        add_rows_full<HT>(acc, base + row * (32 * HT), h);
+    }
+    template <int HT>
+    static __device__ __forceinline__ void store(const f32x16 (&acc)[HT], float* __restrict__ base, int64_t row, int h) {
+        store_rows_full<HT>(acc, base + row * (32 * HT), h);
+    }
+};
+template <>
+struct PRow<CGNN_BF16> {
+    typedef __bf16 elem;
+    template <int HT>
+    static __device__ __forceinline__ void load(f32x16 (&acc)[HT], const __bf16* __restrict__ base, int64_t row, int h) {
+        const bf16x8* p = reinterpret_cast<const bf16x8*>(base + row * (32 * HT) + h * (16 * HT));
+#pragma unroll
+        for (int j = 0; j < 2 * HT; ++j) {
+            const bf16x8 v = p[j];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[j >> 1][8 * (j & 1) + c] = (float)v[c];
+        }
+    }
+    template <int HT>
+    static __device__ __forceinline__ void add(f32x16 (&acc)[HT], const __bf16* __restrict__ base, int64_t row, int h) {
+        const bf16x8* p = reinterpret_cast<const bf16x8*>(base + row * (32 * HT) + h * (16 * HT));
+#pragma unroll
+        for (int j = 0; j < 2 * HT; ++j) {
+            const bf16x8 v = p[j];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[j >> 1][8 * (j & 1) + c] += (float)v[c];
+        }
+    }
+    template <int HT>
+    static __device__ __forceinline__ void store(const f32x16 (&acc)[HT], __bf16* __restrict__ base, int64_t row, int h) {
+        bf16x8* p = reinterpret_cast<bf16x8*>(base + row * (32 * HT) + h * (16 * HT));
+#pragma unroll
+        for (int j = 0; j < 2 * HT; ++j) {
+            bf16x8 v;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = (__bf16)acc[j >> 1][8 * (j & 1) + c];
+            p[j] = v;
+        }
+    }
+};
+
 // Ragged width (dim not a multiple of 32, or unaligned rows): scalar, zero padded.
 template <int T>
 __device__ __forceinline__ void load_rows_ragged(f32x16 (&a)[T], const float* __restrict__ rowp, int dim, int h) {
@@ -276,9 +391,8 @@ __device__ __forceinline__ void store_rows_ragged(const f32x16 (&a)[T], float* _
 
 // LayerNorm over the 32 T features of each row (eps 1e-5, biased variance; two
 // pass: the values are in registers).  A row's features live on lanes r and r+32.
-template <int T>
-__device__ __forceinline__ void layer_norm_rows(f32x16 (&a)[T], const float* __restrict__ gamma,
-                                                const float* __restrict__ beta, int h) {
+template <int T, typename P>
+__device__ __forceinline__ void layer_norm_rows(f32x16 (&a)[T], P gamma, P beta, int h) {
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -301,8 +415,8 @@ __device__ __forceinline__ void layer_norm_rows(f32x16 (&a)[T], const float* __r
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int f = 32 * t + 8 * g + 4 * h;
-            const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + f);
-            const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + f);
+            const f32x4 gm = *(typename VecOf4<P>::type)(gamma + f);
+            const f32x4 bt = *(typename VecOf4<P>::type)(beta + f);
 #pragma unroll
             for (int c = 0; c < 4; ++c) a[t][4 * g + c] = (a[t][4 * g + c] - mean) * rstd * gm[c] + bt[c];
         }

@@ -6,7 +6,8 @@
 // Ps/Pd are the per-node halves of the first Linear (cgnn_project_nodes), so the
 // E x 3D concatenation of the reference is never materialised.  One wave owns 32
 // edges; the edge latent tile is loaded once, kept in registers for the residual,
-// and written once.
+// and written once.  The edge-latent tensors are in the TILED32 layout (include/cgnn.h): every tile moves
+// with lane-linear, fully coalesced 16-byte accesses.
 #include <string.h>
 
 #include "mlp_device.hpp"
@@ -14,8 +15,9 @@
 namespace cgnn {
 
 template <int PREC, bool WLDS, int HT, int DT>
-__global__ __launch_bounds__(CGNN_BLOCK) void edge_block_kernel(MlpDev m, const float* __restrict__ ps,
-                                                                const float* __restrict__ pd,
+__global__ __launch_bounds__(CGNN_BLOCK) void edge_block_kernel(MlpDev m,
+                                                                const typename PRow<PREC>::elem* __restrict__ ps,
+                                                                const typename PRow<PREC>::elem* __restrict__ pd,
                                                                 const int32_t* __restrict__ src,
                                                                 const int32_t* __restrict__ dst, int64_t num_edges,
                                                                 const float* e_in, float* e_out, float* e_upd,
@@ -23,19 +25,19 @@ __global__ __launch_bounds__(CGNN_BLOCK) void edge_block_kernel(MlpDev m, const 
     if (WLDS) stage_weights_to_lds(m, 0);
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int64_t tiles = (num_edges + 31) / 32;
-    constexpr int D = 32 * DT, H = 32 * HT;
+    constexpr int D = 32 * DT;
     const TileRange tr = tile_range(tiles);
     for (int64_t tile = tr.first; tile < tr.end; tile += tr.stride) {
         const int64_t e = tile * 32 + r;
         const int64_t ec = e < num_edges ? e : num_edges - 1;
         const int64_t s = src[ec], d = dst[ec];
         f32x16 ev[DT];
-        load_rows_full<DT>(ev, e_in + ec * D, h);
+        load_tile<DT>(ev, e_in + tile * (32 * D), lane);
         Operand<PREC, HT> oph;
         {
             f32x16 acc[HT];
-            load_rows_full<HT>(acc, ps + s * H, h);
-            add_rows_full<HT>(acc, pd + d * H, h);
+            PRow<PREC>::template load<HT>(acc, ps, s, h);
+            PRow<PREC>::template add<HT>(acc, pd, d, h);
             Operand<PREC, DT> op;
             op.template from_acc<false>(ev);
             dense<DT, HT>(acc, op, WSel<PREC, WLDS>::get(m, 0), lane);
@@ -43,20 +45,85 @@ __global__ __launch_bounds__(CGNN_BLOCK) void edge_block_kernel(MlpDev m, const 
         }
         f32x16 out[DT];
         mlp_tail<PREC, WLDS, HT, DT>(m, oph, out, lane);
-        layer_norm_rows<DT>(out, m.gamma, m.beta, h);
-        if (e < num_edges) {
-            if (e_upd != nullptr) store_rows_full<DT>(out, e_upd + e * D, h);
-            if (residual) {
+        layer_norm_rows<DT>(out, VecSel<WLDS>::gamma(m), VecSel<WLDS>::beta(m), h);
+        // whole tiles are stored: rows past num_edges are padding of the TILED32 buffer
+        if (e_upd != nullptr) store_tile<DT>(out, e_upd + tile * (32 * D), lane);
+        if (residual) {
 #pragma unroll
-                for (int t = 0; t < DT; ++t) out[t] += ev[t];
-            }
-            store_rows_full<DT>(out, e_out + e * D, h);
+            for (int t = 0; t < DT; ++t) out[t] += ev[t];
         }
+        store_tile<DT>(out, e_out + tile * (32 * D), lane);
     }
 }
 
+// bf16 fast path: 512-thread workgroups (two waves per SIMD) sharing one LDS-resident copy of the packed
+// weights, so that one wave's VALU phases (bf16 conversion, LayerNorm, address math) and memory waits overlap
+// the other wave's MFMA phases.  To fit two waves per SIMD (<= 256 registers each) the f32 edge tile is not
+// kept across the MLP: it is converted to the bf16 operand on arrival and re-read (an L2/MALL hit: the tile
+// was streamed in a few microseconds earlier) for the f32 residual.
+#define CGNN_EDGE_LDS_BLOCK 512
+template <int HT, int DT>
+__global__ __launch_bounds__(CGNN_EDGE_LDS_BLOCK) void edge_block_lds_kernel(
+    MlpDev m, const __bf16* __restrict__ ps, const __bf16* __restrict__ pd, const int32_t* __restrict__ src,
+    const int32_t* __restrict__ dst, int64_t num_edges, const float* e_in, float* e_out, float* e_upd, int residual) {
+    stage_weights_to_lds(m, 0);
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int64_t tiles = (num_edges + 31) / 32;
+    constexpr int D = 32 * DT;
+    const TileRange tr = tile_range(tiles);
+    for (int64_t tile = tr.first; tile < tr.end; tile += tr.stride) {
+        const int64_t e = tile * 32 + r;
+        const int64_t ec = e < num_edges ? e : num_edges - 1;
+        const int64_t s = src[ec], d = dst[ec];
+        const float* etile = e_in + tile * (32 * D);
+        Operand<CGNN_BF16, HT> oph;
+        {
+            Operand<CGNN_BF16, DT> op;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                f32x16 a[1];
+                load_tile<1>(a, etile + t * 1024, lane);
+#pragma unroll
+                for (int sidx = 0; sidx < 2; ++sidx)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) op.v[2 * t + sidx][j] = (__bf16)a[0][8 * sidx + j];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // do not let the P gathers pile on top of the e tile in registers
+            f32x16 acc[HT];
+            PRow<CGNN_BF16>::load<HT>(acc, ps, s, h);
+            PRow<CGNN_BF16>::add<HT>(acc, pd, d, h);
+            dense<DT, HT>(acc, op, WSel<CGNN_BF16, true>::get(m, 0), lane);
+            oph.template from_acc<true>(acc);
+        }
+        f32x16 out[DT];
+        mlp_tail<CGNN_BF16, true, HT, DT>(m, oph, out, lane);
+        layer_norm_rows<DT>(out, VecSel<true>::gamma(m), VecSel<true>::beta(m), h);
+        asm volatile("" ::: "memory");   // keep the residual re-read a separate load (no CSE with the first)
+        if (e_upd != nullptr) store_tile<DT>(out, e_upd + tile * (32 * D), lane);
+        if (residual) add_tile<DT>(out, etile, lane);
+        store_tile<DT>(out, e_out + tile * (32 * D), lane);
+    }
+}
+
+template <int HT, int DT>
+static int launch_edge_lds(const MlpDev& m, size_t lds, const __bf16* ps, const __bf16* pd, const int32_t* src,
+                           const int32_t* dst, int64_t num_edges, const float* e_in, float* e_out, float* e_upd,
+                           int residual, hipStream_t st) {
+    auto kern = edge_block_lds_kernel<HT, DT>;
+    if (lds > 48 * 1024) {
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                           "hipFuncSetAttribute(edge_block_lds)");
+        if (rc != CGNN_OK) return rc;
+    }
+    const int grid = grid_for_tiles((num_edges + 31) / 32, 1, CGNN_EDGE_LDS_BLOCK / 64);
+    kern<<<grid, CGNN_EDGE_LDS_BLOCK, lds, st>>>(m, ps, pd, src, dst, num_edges, e_in, e_out, e_upd, residual);
+    return check_hip(hipGetLastError(), "cgnn_edge_block(lds) launch");
+}
+
 template <int PREC, bool WLDS, int HT, int DT>
-static int launch_edge(const MlpDev& m, size_t lds, const float* ps, const float* pd, const int32_t* src,
+static int launch_edge(const MlpDev& m, size_t lds, const typename PRow<PREC>::elem* ps,
+                       const typename PRow<PREC>::elem* pd, const int32_t* src,
                        const int32_t* dst, int64_t num_edges, const float* e_in, float* e_out, float* e_upd,
                        int residual, hipStream_t st) {
     auto kern = edge_block_kernel<PREC, WLDS, HT, DT>;
@@ -75,7 +142,7 @@ static int launch_edge(const MlpDev& m, size_t lds, const float* ps, const float
 
 using namespace cgnn;
 
-extern "C" int cgnn_edge_block(const cgnn_mlp* mlp, const float* ps, const float* pd, const int32_t* src,
+extern "C" int cgnn_edge_block(const cgnn_mlp* mlp, const void* ps, const void* pd, const int32_t* src,
                                const int32_t* dst, int64_t num_edges, const float* e_in, float* e_out, float* e_upd,
                                int32_t residual, int32_t latent, void* stream) {
     MlpDev m;
@@ -111,13 +178,14 @@ extern "C" int cgnn_edge_block(const cgnn_mlp* mlp, const float* ps, const float
 #define CGNN_PAIR(Hh, Dd)                                                                                        \
     if (HT == Hh && DT == Dd) {                                                                                   \
         if (prec == CGNN_F32)                                                                                     \
-            return launch_edge<CGNN_F32, false, Hh, Dd>(m, lds, ps, pd, src, dst, num_edges, e_in, e_out, e_upd,   \
-                                                        residual, st);                                            \
+            return launch_edge<CGNN_F32, false, Hh, Dd>(m, lds, (const float*)ps, (const float*)pd, src, dst,      \
+                                                        num_edges, e_in, e_out, e_upd, residual, st);             \
         if ((Hh <= 4 && Dd <= 4) && want_lds)                                                                     \
-            return launch_edge<CGNN_BF16, (Hh <= 4 && Dd <= 4), Hh, Dd>(m, lds, ps, pd, src, dst, num_edges, e_in, \
-                                                                        e_out, e_upd, residual, st);              \
-        return launch_edge<CGNN_BF16, false, Hh, Dd>(m, lds, ps, pd, src, dst, num_edges, e_in, e_out, e_upd,      \
-                                                     residual, st);                                               \
+            return launch_edge_lds<(Hh <= 4 ? Hh : 1), (Dd <= 4 ? Dd : 1)>(                                        \
+                m, lds, (const __bf16*)ps, (const __bf16*)pd, src, dst, num_edges, e_in, e_out, e_upd, residual,  \
+                st);                                                                                              \
+        return launch_edge<CGNN_BF16, false, Hh, Dd>(m, lds, (const __bf16*)ps, (const __bf16*)pd, src, dst,       \
+                                                     num_edges, e_in, e_out, e_upd, residual, st);                \
     }
     CGNN_FOR_EACH_PAIR(CGNN_PAIR)
 #undef CGNN_PAIR

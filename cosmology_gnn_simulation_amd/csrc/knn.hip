@@ -19,7 +19,7 @@ namespace cgnn {
 
 struct KnnLayout {
     int G;                // cells per axis
-    int64_t cells;        // G^3
+    int64_t cells;        // Gp^3 cell slots, Gp = G rounded up to a power of two (Morton-coded ids)
     size_t off_count, off_start, off_cursor, off_bsum, off_cellof, off_sorted, total;
 };
 
@@ -33,7 +33,9 @@ static KnnLayout knn_layout(int64_t n) {
     if (G < 1) G = 1;
     if (G > 256) G = 256;
     L.G = G;
-    L.cells = (int64_t)G * G * G;
+    int Gp = 1;
+    while (Gp < G) Gp <<= 1;
+    L.cells = (int64_t)Gp * Gp * Gp;
     size_t off = 0;
     L.off_count = off;  off = align256(off + (size_t)(L.cells + 1) * 4);
     L.off_start = off;  off = align256(off + (size_t)(L.cells + 1) * 4);
@@ -44,6 +46,21 @@ static KnnLayout knn_layout(int64_t n) {
     L.off_sorted = off; off = align256(off + (size_t)n * 16);
     L.total = off;
     return L;
+}
+
+// Cells are numbered along a Z-order (Morton) curve, so the cell-sorted particle order -- which the engine
+// adopts as its node numbering -- keeps 3-D neighbours close in memory in all three directions (a row-major
+// cell order leaves x-neighbours a whole slab apart, and the sender gathers then miss L2).
+__device__ __forceinline__ unsigned spread3(unsigned v) {   // 10 bits -> every third bit
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__device__ __forceinline__ int morton3(int x, int y, int z) {
+    return (int)((spread3((unsigned)x) << 2) | (spread3((unsigned)y) << 1) | spread3((unsigned)z));
 }
 
 __device__ __forceinline__ int cell_coord(float p, float inv_h, int G) {
@@ -58,7 +75,7 @@ __global__ void knn_count_kernel(const float* __restrict__ pos, int64_t n, float
     if (i >= n) return;
     const int cx = cell_coord(pos[3 * i + 0], inv_h, G), cy = cell_coord(pos[3 * i + 1], inv_h, G),
               cz = cell_coord(pos[3 * i + 2], inv_h, G);
-    const int cell = (cx * G + cy) * G + cz;
+    const int cell = morton3(cx, cy, cz);
     cell_of[i] = cell;
     atomicAdd(&count[cell], 1);
 }
@@ -136,7 +153,8 @@ __global__ void knn_fill_kernel(const float* __restrict__ pos, int64_t n, const 
 
 template <int K>
 __global__ __launch_bounds__(CGNN_BLOCK) void knn_search_kernel(const float* __restrict__ pos, int64_t n, float box,
-                                                                float h, int G, const int32_t* __restrict__ start,
+                                                                float h, float inv_h, int G,
+                                                                const int32_t* __restrict__ start,
                                                                 const int32_t* __restrict__ cell_of,
                                                                 const float4* __restrict__ sorted,
                                                                 const int32_t* __restrict__ query_ids, int64_t nq,
@@ -146,24 +164,20 @@ __global__ __launch_bounds__(CGNN_BLOCK) void knn_search_kernel(const float* __r
     if (t >= nq) return;
     float qx, qy, qz;
     int64_t out_row;  // row of the outputs this query fills
-    int qcell;
     if (query_ids != nullptr) {
         const int q = query_ids[t];
         qx = pos[3 * (int64_t)q + 0];
         qy = pos[3 * (int64_t)q + 1];
         qz = pos[3 * (int64_t)q + 2];
-        qcell = cell_of[q];
         out_row = t;
     } else {
         const float4 s = sorted[t];  // walk queries in cell order: neighbouring lanes touch the same cells
         qx = s.x;
         qy = s.y;
         qz = s.z;
-        const int q = __float_as_int(s.w);
-        qcell = cell_of[q];
-        out_row = q;
+        out_row = __float_as_int(s.w);
     }
-    const int cz = qcell % G, cy = (qcell / G) % G, cx = qcell / (G * G);
+    const int cx = cell_coord(qx, inv_h, G), cy = cell_coord(qy, inv_h, G), cz = cell_coord(qz, inv_h, G);
 
     float bd[K];
     unsigned bi[K];
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(CGNN_BLOCK) void knn_search_kernel(const float* __r
                     const int wz = uz - sz * G;
                     const float shz = (float)sz * box;
                     const unsigned shift_id = (unsigned)((sx + 1) * 9 + (sy + 1) * 3 + (sz + 1));
-                    const int cell = (wx * G + wy) * G + wz;
+                    const int cell = morton3(wx, wy, wz);
                     const int p0 = start[cell], p1 = start[cell + 1];
                     for (int p = p0; p < p1; ++p) {
                         const float4 c = sorted[p];
@@ -328,7 +342,7 @@ int cgnn_knn_periodic(const float* pos, int64_t n, float box_size, int32_t k, co
     if (nq == 0) return CGNN_OK;
     const unsigned qb = (unsigned)((nq + CGNN_BLOCK - 1) / CGNN_BLOCK);
 #define CGNN_KNN_LAUNCH(KK)                                                                                       \
-    knn_search_kernel<KK><<<qb, CGNN_BLOCK, 0, st>>>(pos, n, box_size, h, G, start, cell_of, sorted, query_ids, nq, \
+    knn_search_kernel<KK><<<qb, CGNN_BLOCK, 0, st>>>(pos, n, box_size, h, inv_h, G, start, cell_of, sorted, query_ids, nq, \
                                                      k, senders, edge_attr)
     if (k <= 8)
         CGNN_KNN_LAUNCH(8);

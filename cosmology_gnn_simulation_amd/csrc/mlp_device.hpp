@@ -17,6 +17,8 @@ struct MlpDev {
     int32_t out_dim[CGNN_MAX_LAYERS];
     uint32_t lds_off[CGNN_MAX_LAYERS];   // byte offset of the layer's packed weights in LDS (WLDS kernels)
     uint32_t bytes[CGNN_MAX_LAYERS];     // packed bytes of the layer
+    uint32_t bias_off[CGNN_MAX_LAYERS];  // byte offset of the layer's bias vector in LDS (WLDS kernels)
+    uint32_t gamma_off, beta_off;        // LayerNorm vectors in LDS (WLDS kernels)
     int32_t nh;                          // hidden layers; layers = nh + 1
     const float* gamma;
     const float* beta;
@@ -55,6 +57,16 @@ inline int make_mlp_dev(const cgnn_mlp* m, MlpDev* d, size_t* lds_bytes, const c
         d->bytes[l] = (uint32_t)nb;
         off += nb;
     }
+    // small vectors (biases, LayerNorm affine) follow the weights in LDS: they are re-read for every tile, and
+    // as global loads they were half of the kernel's vector-memory instructions
+    for (int l = 0; l <= d->nh; ++l) {
+        d->bias_off[l] = (uint32_t)off;
+        off += ((size_t)d->out_dim[l] * 4 + 15) & ~(size_t)15;
+    }
+    d->gamma_off = (uint32_t)off;
+    off += ((size_t)d->out_dim[d->nh] * 4 + 15) & ~(size_t)15;
+    d->beta_off = (uint32_t)off;
+    off += ((size_t)d->out_dim[d->nh] * 4 + 15) & ~(size_t)15;
     d->gamma = m->ln_gamma;
     d->beta = m->ln_beta;
     if ((m->ln_gamma == nullptr) != (m->ln_beta == nullptr)) {
@@ -77,8 +89,37 @@ __device__ __forceinline__ void stage_weights_to_lds(const MlpDev& m, int first_
         const int n16 = (int)(m.bytes[l] >> 4);
         for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
     }
+    for (int l = first_layer; l <= m.nh; ++l) {
+        float* dst = reinterpret_cast<float*>(cgnn_smem + m.bias_off[l]);
+        for (int i = threadIdx.x; i < m.out_dim[l]; i += blockDim.x) dst[i] = m.b[l] ? m.b[l][i] : 0.f;
+    }
+    if (m.gamma != nullptr) {
+        float* g = reinterpret_cast<float*>(cgnn_smem + m.gamma_off);
+        float* b = reinterpret_cast<float*>(cgnn_smem + m.beta_off);
+        for (int i = threadIdx.x; i < m.out_dim[m.nh]; i += blockDim.x) {
+            g[i] = m.gamma[i];
+            b[i] = m.beta[i];
+        }
+    }
     __syncthreads();
 }
+
+typedef const __attribute__((address_space(3))) float* LdsVecPtr;
+
+template <bool WLDS>
+struct VecSel {
+    typedef const float* type;
+    static __device__ __forceinline__ type bias(const MlpDev& m, int l) { return m.b[l]; }
+    static __device__ __forceinline__ type gamma(const MlpDev& m) { return m.gamma; }
+    static __device__ __forceinline__ type beta(const MlpDev& m) { return m.beta; }
+};
+template <>
+struct VecSel<true> {
+    typedef LdsVecPtr type;
+    static __device__ __forceinline__ type bias(const MlpDev& m, int l) { return (LdsVecPtr)(cgnn_smem + m.bias_off[l]); }
+    static __device__ __forceinline__ type gamma(const MlpDev& m) { return (LdsVecPtr)(cgnn_smem + m.gamma_off); }
+    static __device__ __forceinline__ type beta(const MlpDev& m) { return (LdsVecPtr)(cgnn_smem + m.beta_off); }
+};
 
 template <int PREC, bool WLDS>
 struct WSel {
@@ -100,11 +141,11 @@ __device__ __forceinline__ void mlp_tail(const MlpDev& m, Operand<PREC, HT>& oph
     const int h = lane >> 5;
     for (int l = 1; l < m.nh; ++l) {
         f32x16 acc[HT];
-        acc_fill_bias<HT>(acc, m.b[l], m.out_dim[l], h);
+        acc_fill_bias<HT>(acc, VecSel<WLDS>::bias(m, l), m.out_dim[l], h);
         dense<HT, HT>(acc, oph, WSel<PREC, WLDS>::get(m, l), lane);
         oph.template from_acc<true>(acc);
     }
-    acc_fill_bias<OT>(out, m.b[m.nh], m.out_dim[m.nh], h);
+    acc_fill_bias<OT>(out, VecSel<WLDS>::bias(m, m.nh), m.out_dim[m.nh], h);
     dense<HT, OT>(out, oph, WSel<PREC, WLDS>::get(m, m.nh), lane);
 }
 

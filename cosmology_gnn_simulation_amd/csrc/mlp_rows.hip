@@ -9,7 +9,8 @@ namespace cgnn {
 
 template <int PREC, bool WLDS, int K0T, int HT, int OT>
 __global__ __launch_bounds__(CGNN_BLOCK) void mlp_rows_kernel(MlpDev m, const float* __restrict__ x, int64_t n,
-                                                              int ld_x, float* __restrict__ y, int ld_y) {
+                                                              int ld_x, float* __restrict__ y, int ld_y,
+                                                              int y_tiled) {
     if (WLDS) stage_weights_to_lds(m, 0);
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int64_t tiles = (n + 31) / 32;
@@ -32,14 +33,16 @@ __global__ __launch_bounds__(CGNN_BLOCK) void mlp_rows_kernel(MlpDev m, const fl
         Operand<PREC, HT> oph;
         {
             f32x16 acc[HT];
-            acc_fill_bias<HT>(acc, m.b[0], m.out_dim[0], h);
+            acc_fill_bias<HT>(acc, VecSel<WLDS>::bias(m, 0), m.out_dim[0], h);
             dense<K0T, HT>(acc, op0, WSel<PREC, WLDS>::get(m, 0), lane);
             oph.template from_acc<true>(acc);
         }
         f32x16 out[OT];
         mlp_tail<PREC, WLDS, HT, OT>(m, oph, out, lane);
-        if (m.gamma != nullptr) layer_norm_rows<OT>(out, m.gamma, m.beta, h);
-        if (row < n) {
+        if (m.gamma != nullptr) layer_norm_rows<OT>(out, VecSel<WLDS>::gamma(m), VecSel<WLDS>::beta(m), h);
+        if (y_tiled) {
+            store_tile<OT>(out, y + tile * (1024 * OT), lane);
+        } else if (row < n) {
             if (out_full)
                 store_rows_full<OT>(out, y + row * ld_y, h);
             else
@@ -51,7 +54,8 @@ __global__ __launch_bounds__(CGNN_BLOCK) void mlp_rows_kernel(MlpDev m, const fl
 template <int PREC, int DT, int HT>
 __global__ __launch_bounds__(CGNN_BLOCK) void project_kernel(const void* ws, const void* wd, const float* __restrict__ bd,
                                                              int hidden, const float* __restrict__ x, int64_t n,
-                                                             float* __restrict__ ps, float* __restrict__ pd) {
+                                                             typename PRow<PREC>::elem* __restrict__ ps,
+                                                             typename PRow<PREC>::elem* __restrict__ pd) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int64_t tiles = (n + 31) / 32;
     constexpr unsigned wbytes = DT * HT * 1024 * (PREC == CGNN_BF16 ? 2 : 4);
@@ -68,22 +72,22 @@ __global__ __launch_bounds__(CGNN_BLOCK) void project_kernel(const void* ws, con
         }
         if (ps != nullptr) {
             f32x16 acc[HT];
-            acc_fill_bias<HT>(acc, nullptr, hidden, h);
+            acc_fill_bias<HT>(acc, (const float*)nullptr, hidden, h);
             dense<DT, HT>(acc, op, wsrc_s, lane);
-            if (row < n) store_rows_full<HT>(acc, ps + row * (32 * HT), h);
+            if (row < n) PRow<PREC>::template store<HT>(acc, ps, row, h);
         }
         if (pd != nullptr) {
             f32x16 acc[HT];
             acc_fill_bias<HT>(acc, bd, hidden, h);
             dense<DT, HT>(acc, op, wsrc_d, lane);
-            if (row < n) store_rows_full<HT>(acc, pd + row * (32 * HT), h);
+            if (row < n) PRow<PREC>::template store<HT>(acc, pd, row, h);
         }
     }
 }
 
 template <int PREC, bool WLDS, int K0T, int HT, int OT>
 static int launch_mlp_rows(const MlpDev& m, size_t lds, const float* x, int64_t n, int ld_x, float* y, int ld_y,
-                           hipStream_t st) {
+                           int y_tiled, hipStream_t st) {
     auto kern = mlp_rows_kernel<PREC, WLDS, K0T, HT, OT>;
     if (WLDS && lds > 48 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -92,17 +96,17 @@ static int launch_mlp_rows(const MlpDev& m, size_t lds, const float* x, int64_t 
         if (rc != CGNN_OK) return rc;
     }
     int grid = grid_for_tiles((n + 31) / 32, WLDS ? 1 : 2);
-    kern<<<grid, CGNN_BLOCK, WLDS ? lds : 0, st>>>(m, x, n, ld_x, y, ld_y);
+    kern<<<grid, CGNN_BLOCK, WLDS ? lds : 0, st>>>(m, x, n, ld_x, y, ld_y, y_tiled);
     return check_hip(hipGetLastError(), "cgnn_mlp_rows launch");
 }
 
 template <int PREC, int K0T, int HT, int OT>
 static int dispatch_lds(const MlpDev& m, size_t lds, const float* x, int64_t n, int ld_x, float* y, int ld_y,
-                        hipStream_t st) {
+                        int y_tiled, hipStream_t st) {
     if (PREC == CGNN_BF16 && HT <= 4 && OT <= 4 && K0T <= 4 && lds <= CGNN_LDS_WEIGHT_BUDGET && n >= 4096)
         return launch_mlp_rows<PREC, (PREC == CGNN_BF16 && HT <= 4 && OT <= 4 && K0T <= 4), K0T, HT, OT>(
-            m, lds, x, n, ld_x, y, ld_y, st);
-    return launch_mlp_rows<PREC, false, K0T, HT, OT>(m, lds, x, n, ld_x, y, ld_y, st);
+            m, lds, x, n, ld_x, y, ld_y, y_tiled, st);
+    return launch_mlp_rows<PREC, false, K0T, HT, OT>(m, lds, x, n, ld_x, y, ld_y, y_tiled, st);
 }
 
 }  // namespace cgnn
@@ -112,7 +116,7 @@ using namespace cgnn;
 extern "C" {
 
 int cgnn_mlp_rows(const cgnn_mlp* mlp, const float* x, int64_t n, int32_t ld_x, float* y, int32_t ld_y,
-                  void* stream) {
+                  int32_t y_layout, void* stream) {
     MlpDev m;
     size_t lds = 0;
     int rc = make_mlp_dev(mlp, &m, &lds, "cgnn_mlp_rows");
@@ -139,11 +143,21 @@ int cgnn_mlp_rows(const cgnn_mlp* mlp, const float* x, int64_t n, int32_t ld_x, 
         set_error("cgnn_mlp_rows: LayerNorm width %d must be a multiple of 32", m.out_dim[m.nh]);
         return CGNN_ERR_UNSUPPORTED;
     }
+    if (y_layout != CGNN_ROWS && y_layout != CGNN_TILED32) {
+        set_error("cgnn_mlp_rows: unknown y_layout %d", y_layout);
+        return CGNN_ERR_INVALID_ARG;
+    }
+    const int y_tiled = y_layout == CGNN_TILED32;
+    if (y_tiled && m.out_dim[m.nh] != 32 * OT) {
+        set_error("cgnn_mlp_rows: CGNN_TILED32 output needs a width that is a multiple of 32 (got %d)",
+                  m.out_dim[m.nh]);
+        return CGNN_ERR_UNSUPPORTED;
+    }
     hipStream_t st = (hipStream_t)stream;
     const int prec = mlp->precision;
 #define CGNN_TRY(P, K, H, O)                                                              \
     if (prec == P && K0T == K && HT == H && OT == O)                                       \
-        return dispatch_lds<P, K, H, O>(m, lds, x, n, ld_x, y, ld_y, st);
+        return dispatch_lds<P, K, H, O>(m, lds, x, n, ld_x, y, ld_y, y_tiled, st);
     // encoders: narrow input (<= 32 features) -> latent ; decoders: latent -> <= 32 outputs
 #define CGNN_PAIR(H, D)               \
     CGNN_TRY(CGNN_F32, 1, H, D)       \
@@ -160,7 +174,7 @@ int cgnn_mlp_rows(const cgnn_mlp* mlp, const float* x, int64_t n, int32_t ld_x, 
 }
 
 int cgnn_project_nodes(const cgnn_linear* ws, const cgnn_linear* wd, int32_t precision, const float* x, int64_t n,
-                       float* ps, float* pd, void* stream) {
+                       void* ps, void* pd, void* stream) {
     if (!x || n < 0 || (!ps && !pd) || (ps && (!ws || !ws->w)) || (pd && (!wd || !wd->w))) {
         set_error("cgnn_project_nodes: invalid argument");
         return CGNN_ERR_INVALID_ARG;
@@ -185,9 +199,11 @@ int cgnn_project_nodes(const cgnn_linear* ws, const cgnn_linear* wd, int32_t pre
 #define CGNN_PAIR(Hh, Dd)                                                                                       \
     if (HT == Hh && DT == Dd) {                                                                                  \
         if (precision == CGNN_F32)                                                                               \
-            project_kernel<CGNN_F32, Dd, Hh><<<grid, CGNN_BLOCK, 0, st>>>(wsp, wdp, bd, H, x, n, ps, pd);         \
+            project_kernel<CGNN_F32, Dd, Hh><<<grid, CGNN_BLOCK, 0, st>>>(wsp, wdp, bd, H, x, n, (float*)ps,     \
+                                                                          (float*)pd);                           \
         else if (precision == CGNN_BF16)                                                                         \
-            project_kernel<CGNN_BF16, Dd, Hh><<<grid, CGNN_BLOCK, 0, st>>>(wsp, wdp, bd, H, x, n, ps, pd);        \
+            project_kernel<CGNN_BF16, Dd, Hh><<<grid, CGNN_BLOCK, 0, st>>>(wsp, wdp, bd, H, x, n, (__bf16*)ps,   \
+                                                                           (__bf16*)pd);                         \
         else {                                                                                                   \
             set_error("cgnn_project_nodes: unknown precision %d", precision);                                    \
             return CGNN_ERR_INVALID_ARG;                                                                         \

@@ -36,8 +36,8 @@ static int num_cus() {
 }
 
 // One wave owns one 32-row tile at a time; blocks are persistent (grid-stride).
-int grid_for_tiles(int64_t tiles, int blocks_per_cu) {
-    int64_t blocks = (tiles + CGNN_WAVES_PER_BLOCK - 1) / CGNN_WAVES_PER_BLOCK;
+int grid_for_tiles(int64_t tiles, int blocks_per_cu, int waves_per_block) {
+    int64_t blocks = (tiles + waves_per_block - 1) / waves_per_block;
     const int64_t cap = (int64_t)num_cus() * blocks_per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
@@ -100,11 +100,51 @@ __global__ void aggregate_fixedk_kernel(const float* __restrict__ table, const i
     }
 }
 
+// float offset of the 16-byte chunk c (features 4c..4c+3) of row e in a TILED32 matrix of `chunks` chunks/row
+__device__ __forceinline__ int64_t tiled_chunk_offset(int64_t e, int c, int chunks) {
+    const int q = c >> 1, hh = c & 1;   // q = 4t + g
+    return (e >> 5) * ((int64_t)chunks * 128) + (((int64_t)q * 64 + 32 * hh + (e & 31)) << 2);
+}
+
+// Per-edge messages in TILED32 layout, fixed in-degree: the k chunks a thread sums are contiguous 16-byte
+// pieces (consecutive edges of a receiver sit on consecutive lanes' slots of the tile).
+__global__ void aggregate_fixedk_tiled_kernel(const float* __restrict__ table, int k, int64_t num_nodes, int chunks,
+                                              float* __restrict__ out) {
+    const int64_t total = num_nodes * chunks;
+    for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
+         gid += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = gid / chunks;
+        const int c = (int)(gid - row * chunks);
+        const int64_t e0 = row * k;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int j = 0; j < k; ++j) acc += *reinterpret_cast<const f32x4*>(table + tiled_chunk_offset(e0 + j, c, chunks));
+        *reinterpret_cast<f32x4*>(out + gid * 4) = acc;
+    }
+}
+
+__global__ void relayout_kernel(const float* __restrict__ src, int from_tiled, float* __restrict__ dst, int to_tiled,
+                                int64_t n, int64_t n_pad, int chunks) {
+    const int64_t total = n_pad * chunks;
+    for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
+         gid += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = gid / chunks;
+        const int c = (int)(gid - row * chunks);
+        const int64_t so = from_tiled ? tiled_chunk_offset(row, c, chunks) : gid * 4;
+        const int64_t dt = to_tiled ? tiled_chunk_offset(row, c, chunks) : gid * 4;
+        if (row < n)
+            *reinterpret_cast<f32x4*>(dst + dt) = *reinterpret_cast<const f32x4*>(src + so);
+        else if (to_tiled)
+            *reinterpret_cast<f32x4*>(dst + dt) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 // General edge list: each group of `chunks` lanes walks a contiguous run of edges
 // and flushes one atomic row per destination change.
-__global__ void aggregate_atomic_kernel(const float* __restrict__ table, const int32_t* __restrict__ gather,
-                                        const int32_t* __restrict__ dst, int64_t num_edges, int chunks,
-                                        int edges_per_group, float* __restrict__ out) {
+__global__ void aggregate_atomic_kernel(const float* __restrict__ table, int table_tiled,
+                                        const int32_t* __restrict__ gather, const int32_t* __restrict__ dst,
+                                        int64_t num_edges, int chunks, int edges_per_group,
+                                        float* __restrict__ out) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t group = gid / chunks;
     const int c = (int)(gid - group * chunks);
@@ -125,7 +165,8 @@ __global__ void aggregate_atomic_kernel(const float* __restrict__ table, const i
             cur = d;
         }
         const int64_t idx = gather ? (int64_t)gather[e] : e;
-        acc += *reinterpret_cast<const f32x4*>(table + (idx * chunks + c) * 4);
+        acc += *reinterpret_cast<const f32x4*>(table + (table_tiled ? tiled_chunk_offset(idx, c, chunks)
+                                                                    : (idx * chunks + c) * 4));
     }
     float* o = out + ((int64_t)cur * chunks + c) * 4;
     atomicAdd(o + 0, acc[0]);
@@ -257,14 +298,46 @@ int cgnn_pack_linear(const float* w, int32_t out_dim, int32_t ld, int32_t col0, 
     return check_hip(hipGetLastError(), "cgnn_pack_linear launch");
 }
 
-int cgnn_aggregate(const float* table, const int32_t* gather, const int32_t* dst, int64_t num_edges,
-                   int32_t fixed_k, int64_t num_nodes, int32_t width, float* out, void* stream) {
+int64_t cgnn_tiled_rows(int64_t n) { return n <= 0 ? 0 : ((n + 31) / 32) * 32; }
+
+int cgnn_relayout(const float* src, int32_t from, float* dst, int32_t to, int64_t n, int32_t width, void* stream) {
+    if (!src || !dst || n < 0 || width <= 0 || (from != CGNN_ROWS && from != CGNN_TILED32) ||
+        (to != CGNN_ROWS && to != CGNN_TILED32)) {
+        set_error("cgnn_relayout: invalid argument");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if ((from == CGNN_TILED32 || to == CGNN_TILED32) && width % 32 != 0) {
+        set_error("cgnn_relayout: CGNN_TILED32 needs width %% 32 == 0 (got %d)", width);
+        return CGNN_ERR_UNSUPPORTED;
+    }
+    if (width % 4 != 0) {
+        set_error("cgnn_relayout: width %d is not a multiple of 4", width);
+        return CGNN_ERR_UNSUPPORTED;
+    }
+    if (n == 0) return CGNN_OK;
+    const int64_t n_pad = to == CGNN_TILED32 ? cgnn_tiled_rows(n) : n;
+    relayout_kernel<<<blocks_for(n_pad * (width / 4), 32), CGNN_BLOCK, 0, (hipStream_t)stream>>>(
+        src, from == CGNN_TILED32, dst, to == CGNN_TILED32, n, n_pad, width / 4);
+    return check_hip(hipGetLastError(), "cgnn_relayout launch");
+}
+
+int cgnn_aggregate(const float* table, int32_t table_layout, const int32_t* gather, const int32_t* dst,
+                   int64_t num_edges, int32_t fixed_k, int64_t num_nodes, int32_t width, float* out, void* stream) {
     if (!table || !out || num_edges < 0 || num_nodes < 0 || width <= 0 || fixed_k < 0) {
         set_error("cgnn_aggregate: invalid argument");
         return CGNN_ERR_INVALID_ARG;
     }
     if (width % 4 != 0) {
         set_error("cgnn_aggregate: width %d is not a multiple of 4", width);
+        return CGNN_ERR_UNSUPPORTED;
+    }
+    const int tiled = table_layout == CGNN_TILED32;
+    if (table_layout != CGNN_ROWS && !tiled) {
+        set_error("cgnn_aggregate: unknown table_layout %d", table_layout);
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if (tiled && (gather != nullptr || width % 32 != 0)) {
+        set_error("cgnn_aggregate: CGNN_TILED32 tables are per-edge messages (gather == NULL, width %% 32 == 0)");
         return CGNN_ERR_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -276,8 +349,12 @@ int cgnn_aggregate(const float* table, const int32_t* gather, const int32_t* dst
                       (long long)num_edges, (long long)(num_nodes * fixed_k));
             return CGNN_ERR_INVALID_ARG;
         }
-        aggregate_fixedk_kernel<<<blocks_for(num_nodes * chunks, 64), CGNN_BLOCK, 0, st>>>(table, gather, fixed_k,
-                                                                                        num_nodes, chunks, out);
+        if (tiled)
+            aggregate_fixedk_tiled_kernel<<<blocks_for(num_nodes * chunks, 64), CGNN_BLOCK, 0, st>>>(
+                table, fixed_k, num_nodes, chunks, out);
+        else
+            aggregate_fixedk_kernel<<<blocks_for(num_nodes * chunks, 64), CGNN_BLOCK, 0, st>>>(
+                table, gather, fixed_k, num_nodes, chunks, out);
         return check_hip(hipGetLastError(), "cgnn_aggregate(fixed_k) launch");
     }
     if (!dst && num_edges > 0) {
@@ -290,7 +367,8 @@ int cgnn_aggregate(const float* table, const int32_t* gather, const int32_t* dst
     const int64_t groups = (num_edges + epg - 1) / epg;
     const int64_t threads = groups * chunks;
     const int64_t blocks = (threads + CGNN_BLOCK - 1) / CGNN_BLOCK;
-    aggregate_atomic_kernel<<<(unsigned)blocks, CGNN_BLOCK, 0, st>>>(table, gather, dst, num_edges, chunks, epg, out);
+    aggregate_atomic_kernel<<<(unsigned)blocks, CGNN_BLOCK, 0, st>>>(table, tiled, gather, dst, num_edges, chunks, epg,
+                                                                     out);
     return check_hip(hipGetLastError(), "cgnn_aggregate(atomic) launch");
 }
 

@@ -194,11 +194,12 @@ class ShardedForward:
 
     def _buffers(self, D: int, H: int, dev):
         sh = self.sh
-        key = (D, H, dev)
+        key = (D, H, dev, self.model.edge_precision)
         if self._bufs is None or self._bufs[0] != key:
             x_all = torch.empty((sh.n_local, D), dtype=torch.float32, device=dev)
-            ps = torch.empty((sh.n_local, H), dtype=torch.float32, device=dev)
-            pd = torch.empty((sh.n_owned, H), dtype=torch.float32, device=dev)
+            pdt = ops.p_table_dtype(self.model.edge_precision)
+            ps = torch.empty((sh.n_local, H), dtype=pdt, device=dev)
+            pd = torch.empty((sh.n_owned, H), dtype=pdt, device=dev)
             agg = torch.empty((sh.n_owned, D), dtype=torch.float32, device=dev)
             self._bufs = (key, x_all, ps, pd, agg)
         return self._bufs[1:]
@@ -212,8 +213,8 @@ class ShardedForward:
         self.P = P
         self.x_all, self.ps, self.pd, self.agg = self._buffers(D, H, sh.x_feat.device)
         ops.mlp_rows(P["enc_node"], sh.x_feat, out=self.x_all[:sh.n_owned])
-        self.el = ops.mlp_rows(P["enc_edge"], sh.edge_attr)
-        self.e_upd = torch.empty_like(self.el) if m.message_source == "edge" else None
+        self.el = ops.mlp_rows(P["enc_edge"], sh.edge_attr, tiled=True)
+        self.e_upd = self.el.empty_like() if m.message_source == "edge" else None
 
     def round(self, i: int):
         m, sh = self.model, self.sh

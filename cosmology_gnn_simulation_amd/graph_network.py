@@ -241,7 +241,7 @@ def _run_round(p: _PackedProcessor, x: torch.Tensor, e: torch.Tensor, src, dst, 
         ps, pd, agg, e_upd = scratch
     ps, pd = ops.project_nodes(p.ws, p.wd, x, ps, pd)
     if message_source == "edge" and e_upd is None:
-        e_upd = torch.empty_like(e)
+        e_upd = e.empty_like()
     e_new = ops.edge_block(p.edge, ps, pd, src, dst, e, e_out, e_upd if message_source == "edge" else None, residual)
     if message_source == "x_j":
         agg = ops.aggregate(x, src, dst, n, fixed_k, src.numel(), agg)
@@ -291,9 +291,10 @@ class InteractionNetwork(nn.Module):
         with torch.no_grad():
             src, dst, fixed_k = _graph_arrays(data, x.shape[0])
             p = self._pack(x.shape[1])
-            xf, ef = x.float().contiguous(), edge_attr.float().contiguous()
+            xf = x.float().contiguous()
+            ef = ops.TiledRows.from_rows(edge_attr.float().contiguous())     # engine-internal edge layout
             new_x, new_e = _run_round(p, xf, ef, src, dst, fixed_k, self.message_source, residual=False)
-        out = Data(x=new_x, edge_index=data.edge_index, edge_attr=new_e)
+        out = Data(x=new_x, edge_index=data.edge_index, edge_attr=new_e.to_rows())
         if hasattr(data, "globals"):
             out.globals = data.globals
         for hint in ("_cgnn_fixed_k", "_cgnn_graph"):
@@ -394,15 +395,16 @@ class EncodeProcessDecode(nn.Module):
                 edge_attr = ops.gather_rows(edge_attr.view(n, -1), order).view(n * fixed_k, -1)
             P = self._pack(x.shape[1], edge_attr.shape[1])
             xl = ops.mlp_rows(P["enc_node"], x)
-            el = ops.mlp_rows(P["enc_edge"], edge_attr)
+            el = ops.mlp_rows(P["enc_edge"], edge_attr, tiled=True)      # edge latents live in TILED32 layout
             H = P["rounds"][0].ws.out_dim if P["rounds"] else 0
             scratch = None
             if P["rounds"]:
                 dev = x.device
-                ps = torch.empty((n, H), dtype=torch.float32, device=dev)
-                pd = torch.empty((n, H), dtype=torch.float32, device=dev)
+                pdt = ops.p_table_dtype(self.edge_precision)
+                ps = torch.empty((n, H), dtype=pdt, device=dev)
+                pd = torch.empty((n, H), dtype=pdt, device=dev)
                 agg = torch.empty((n, xl.shape[1]), dtype=torch.float32, device=dev)
-                e_upd = torch.empty_like(el) if self.message_source == "edge" else None
+                e_upd = el.empty_like() if self.message_source == "edge" else None
                 scratch = (ps, pd, agg, e_upd)
             for p in P["rounds"]:
                 # residual streams updated in place (reference graph_network.py:181-182)
@@ -410,11 +412,11 @@ class EncodeProcessDecode(nn.Module):
                                     x_out=xl, e_out=el, scratch=scratch)
             out = {"acceleration": ops.mlp_rows(P["dec_acc"], xl), "temp_rate": ops.mlp_rows(P["dec_tr"], xl)}
             if want_latents:
-                out["x_latent"], out["edge_latent"] = xl, el
+                out["x_latent"], out["edge_latent"] = xl, el.to_rows()
             if plan is not None:   # back to the caller's particle numbering
                 out["acceleration"] = ops.gather_rows(out["acceleration"], inv)
                 out["temp_rate"] = ops.gather_rows(out["temp_rate"], inv)
                 if want_latents:
                     out["x_latent"] = ops.gather_rows(xl, inv)
-                    out["edge_latent"] = ops.gather_rows(el.view(n, -1), inv).view(n * fixed_k, -1)
+                    out["edge_latent"] = ops.gather_rows(out["edge_latent"].view(n, -1), inv).view(n * fixed_k, -1)
         return out

@@ -125,16 +125,73 @@ class PackedMLP:
         return self._struct
 
 
-def mlp_rows(mlp: PackedMLP, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+class TiledRows:
+    """An ``[n, width]`` float32 matrix in the engine's TILED32 layout (``cgnn_layout`` in include/cgnn.h):
+    32-row tiles stored in MFMA-accumulator order so that a wavefront moves a tile with fully coalesced
+    accesses.  ``buf`` has ``tiled_rows(n)`` rows; only the kernels interpret its bytes."""
+
+    def __init__(self, n: int, width: int, device, buf: Optional[torch.Tensor] = None):
+        if width % 32:
+            raise CgnnError(f"TILED32 needs a width that is a multiple of 32 (got {width})")
+        self.n, self.width = int(n), int(width)
+        rows = ((self.n + 31) // 32) * 32
+        self.buf = buf if buf is not None else torch.empty((rows, width), dtype=torch.float32, device=device)
+        if self.buf.shape != (rows, width) or not self.buf.is_contiguous():
+            raise CgnnError("TiledRows: buffer has the wrong shape")
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    def empty_like(self) -> "TiledRows":
+        return TiledRows(self.n, self.width, self.buf.device)
+
+    def to_rows(self) -> torch.Tensor:
+        return relayout(self)
+
+    @staticmethod
+    def from_rows(x: torch.Tensor) -> "TiledRows":
+        return relayout(x)
+
+
+def relayout(x):
+    """``TiledRows -> row-major tensor`` or ``row-major tensor -> TiledRows``."""
+    lib = _lib.load()
+    if isinstance(x, TiledRows):
+        out = torch.empty((x.n, x.width), dtype=torch.float32, device=x.device)
+        if x.n:
+            check(lib.cgnn_relayout(x.buf.data_ptr(), _lib.TILED32, out.data_ptr(), _lib.ROWS, x.n, x.width,
+                                    stream_ptr(x.device)), "cgnn_relayout")
+        return out
+    x = f32c(x, "x")
+    t = TiledRows(x.shape[0], x.shape[1], x.device)
+    if t.n:
+        check(lib.cgnn_relayout(x.data_ptr(), _lib.ROWS, t.buf.data_ptr(), _lib.TILED32, t.n, t.width,
+                                stream_ptr(x.device)), "cgnn_relayout")
+    return t
+
+
+def mlp_rows(mlp: PackedMLP, x: torch.Tensor, out=None, tiled: bool = False):
+    """Row-wise MLP.  ``tiled=True`` (or ``out`` a :class:`TiledRows`) writes the result in TILED32 layout."""
     x = f32c(x, "x")
     n = x.shape[0]
     if x.dim() != 2 or x.shape[1] != mlp.in_dim:
         raise CgnnError(f"mlp_rows: input is {tuple(x.shape)}, the MLP expects [n, {mlp.in_dim}]")
-    y = out if out is not None else torch.empty((n, mlp.out_dim), dtype=torch.float32, device=x.device)
+    if tiled or isinstance(out, TiledRows):
+        y = out if out is not None else TiledRows(n, mlp.out_dim, x.device)
+        yb, layout = y.buf, _lib.TILED32
+    else:
+        y = out if out is not None else torch.empty((n, mlp.out_dim), dtype=torch.float32, device=x.device)
+        yb, layout = y, _lib.ROWS
     with _timed("mlp_rows", x.device):
-        check(_lib.load().cgnn_mlp_rows(C.byref(mlp.struct()), x.data_ptr(), n, x.stride(0), y.data_ptr(), y.stride(0),
-                                    stream_ptr(x.device)), "cgnn_mlp_rows")
+        check(_lib.load().cgnn_mlp_rows(C.byref(mlp.struct()), x.data_ptr(), n, x.stride(0), yb.data_ptr(),
+                                        yb.stride(0), layout, stream_ptr(x.device)), "cgnn_mlp_rows")
     return y
+
+
+def p_table_dtype(precision) -> torch.dtype:
+    """Element type of the Ps/Pd gather tables (engine-internal layout, see include/cgnn.h)."""
+    return torch.bfloat16 if _prec(precision) == BF16 else torch.float32
 
 
 def project_nodes(ws: Optional[PackedLinear], wd: Optional[PackedLinear], x: torch.Tensor,
@@ -142,10 +199,14 @@ def project_nodes(ws: Optional[PackedLinear], wd: Optional[PackedLinear], x: tor
     x = f32c(x, "x")
     n = x.shape[0]
     ref = ws if ws is not None else wd
+    pdt = p_table_dtype(ref.precision)
     if ws is not None and ps is None:
-        ps = torch.empty((n, ws.out_dim), dtype=torch.float32, device=x.device)
+        ps = torch.empty((n, ws.out_dim), dtype=pdt, device=x.device)
     if wd is not None and pd is None:
-        pd = torch.empty((n, wd.out_dim), dtype=torch.float32, device=x.device)
+        pd = torch.empty((n, wd.out_dim), dtype=pdt, device=x.device)
+    for t in (ps, pd):
+        if t is not None and (t.dtype != pdt or not t.is_contiguous()):
+            raise CgnnError(f"project_nodes: tables must be contiguous {pdt} for this precision")
     s1 = ws.struct() if ws is not None else None
     s2 = wd.struct() if wd is not None else None
     with _timed("project_nodes", x.device):
@@ -157,41 +218,52 @@ def project_nodes(ws: Optional[PackedLinear], wd: Optional[PackedLinear], x: tor
 
 
 def edge_block(mlp: PackedMLP, ps: torch.Tensor, pd: torch.Tensor, src: torch.Tensor, dst: torch.Tensor,
-               e_in: torch.Tensor, e_out: Optional[torch.Tensor] = None, e_upd: Optional[torch.Tensor] = None,
-               residual: bool = True) -> torch.Tensor:
-    e_in = f32c(e_in, "edge latents")
+               e_in: TiledRows, e_out: Optional[TiledRows] = None, e_upd: Optional[TiledRows] = None,
+               residual: bool = True) -> TiledRows:
+    """Fused edge update on TILED32 edge latents (``e_out`` may be ``e_in`` for the in-place residual)."""
+    if not isinstance(e_in, TiledRows):
+        raise CgnnError("edge_block: edge latents must be TiledRows (use ops.relayout / TiledRows.from_rows)")
     src, dst = i32c(src, "src"), i32c(dst, "dst")
-    ne, latent = e_in.shape
+    ne, latent = e_in.n, e_in.width
     if e_out is None:
-        e_out = torch.empty_like(e_in)
-    for t, name in ((ps, "ps"), (pd, "pd"), (e_out, "e_out")):
+        e_out = e_in.empty_like()
+    for t, name in ((ps, "ps"), (pd, "pd")):
         require_device(t, name)
-        if not t.is_contiguous() or t.dtype != torch.float32:
-            raise CgnnError(f"edge_block: {name} must be contiguous float32")
+        if not t.is_contiguous() or t.dtype != p_table_dtype(mlp.precision):
+            raise CgnnError(f"edge_block: {name} must be a contiguous project_nodes table of the MLP's precision")
+    for t in (e_out, e_upd):
+        if t is not None and (t.n != ne or t.width != latent):
+            raise CgnnError("edge_block: e_out / e_upd do not match the edge latents")
     if src.numel() != ne or dst.numel() != ne:
         raise CgnnError("edge_block: src/dst length does not match the edge latents")
     with _timed("edge_block", e_in.device):
         check(_lib.load().cgnn_edge_block(C.byref(mlp.struct()), ps.data_ptr(), pd.data_ptr(), src.data_ptr(),
-                                      dst.data_ptr(), ne, e_in.data_ptr(), e_out.data_ptr(), ptr(e_upd),
-                                      1 if residual else 0, latent, stream_ptr(e_in.device)), "cgnn_edge_block")
+                                          dst.data_ptr(), ne, e_in.buf.data_ptr(), e_out.buf.data_ptr(),
+                                          None if e_upd is None else e_upd.buf.data_ptr(),
+                                          1 if residual else 0, latent, stream_ptr(e_in.device)), "cgnn_edge_block")
     return e_out
 
 
-def aggregate(table: torch.Tensor, gather: Optional[torch.Tensor], dst: Optional[torch.Tensor], num_nodes: int,
+def aggregate(table, gather: Optional[torch.Tensor], dst: Optional[torch.Tensor], num_nodes: int,
               fixed_k: int = 0, num_edges: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    table = f32c(table, "table")
-    width = table.shape[1]
+    """``out[i] = sum_{e: dst[e]==i} table[gather[e] if gather is not None else e]``.  ``table`` is a row-major
+    tensor, or a :class:`TiledRows` of per-edge messages (``gather`` must then be ``None``)."""
+    if isinstance(table, TiledRows):
+        tb, layout, width, dev, nrows = table.buf, _lib.TILED32, table.width, table.device, table.n
+    else:
+        table = f32c(table, "table")
+        tb, layout, width, dev, nrows = table, _lib.ROWS, table.shape[1], table.device, table.shape[0]
     if gather is not None:
         gather = i32c(gather, "gather")
     if dst is not None:
         dst = i32c(dst, "dst")
     if num_edges is None:
-        num_edges = gather.numel() if gather is not None else (dst.numel() if dst is not None else table.shape[0])
+        num_edges = gather.numel() if gather is not None else (dst.numel() if dst is not None else nrows)
     if out is None:
-        out = torch.empty((num_nodes, width), dtype=torch.float32, device=table.device)
-    with _timed("aggregate", table.device):
-        check(_lib.load().cgnn_aggregate(table.data_ptr(), ptr(gather), ptr(dst), num_edges, fixed_k, num_nodes, width,
-                                     out.data_ptr(), stream_ptr(table.device)), "cgnn_aggregate")
+        out = torch.empty((num_nodes, width), dtype=torch.float32, device=dev)
+    with _timed("aggregate", dev):
+        check(_lib.load().cgnn_aggregate(tb.data_ptr(), layout, ptr(gather), ptr(dst), num_edges, fixed_k, num_nodes,
+                                         width, out.data_ptr(), stream_ptr(dev)), "cgnn_aggregate")
     return out
 
 

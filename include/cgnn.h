@@ -45,6 +45,18 @@ typedef enum {
     CGNN_BF16 = 1   /* bf16 operands, v_mfma_f32_32x32x16_bf16, f32 accumulate       */
 } cgnn_precision;
 
+/*
+ * Memory layout of an [n, width] float32 matrix.
+ * CGNN_ROWS    dense row-major.
+ * CGNN_TILED32 (width % 32 == 0) whole tiles of 32 rows; element (32*T + r, 32*t + 8*g + 4*h + c), g<4, h<2,
+ *              c<4, lives at float offset  T*32*width + ((4*t + g)*64 + 32*h + r)*4 + c.  A wavefront then
+ *              moves its 32-row tile with width/8 fully coalesced 1-KiB instructions in exactly the register
+ *              order of the MFMA accumulators.  The buffer holds cgnn_tiled_rows(n) >= n rows (padding rows
+ *              are scratch).  Used for the edge-latent stream, which never leaves the engine; convert with
+ *              cgnn_relayout at the API boundary.
+ */
+typedef enum { CGNN_ROWS = 0, CGNN_TILED32 = 1 } cgnn_layout;
+
 /* One Linear layer, weights already in MFMA-fragment order (cgnn_pack_linear). */
 typedef struct {
     const void* w;      /* packed weights, cgnn_packed_linear_bytes() long */
@@ -84,14 +96,23 @@ int cgnn_pack_linear(const float* w, int32_t out_dim, int32_t ld, int32_t col0, 
  * y[n, out] = MLP(x[n, in]) ; reference graph_network.py:54,57 (encoder),
  * :158-159 (decoders).  ld_x / ld_y are row strides in floats. */
 int cgnn_mlp_rows(const cgnn_mlp* mlp, const float* x, int64_t n, int32_t ld_x,
-                  float* y, int32_t ld_y, void* stream);
+                  float* y, int32_t ld_y, int32_t y_layout, void* stream);
+
+/* rows of a CGNN_TILED32 buffer holding n logical rows (n rounded up to 32) */
+int64_t cgnn_tiled_rows(int64_t n);
+/* dst (layout `to`) = src (layout `from`), logical shape [n, width]; padding rows of a tiled dst are zeroed. */
+int cgnn_relayout(const float* src, int32_t from, float* dst, int32_t to, int64_t n, int32_t width, void* stream);
 
 /* ---- first-layer split: per-node projections consumed by cgnn_edge_block ------
  * ps[n,H] = x[n,D] * Ws^T ; pd[n,H] = x[n,D] * Wd^T + b1, where [Ws|Wd|We] is the
  * column split of the edge model's first Linear (reference graph_network.py:89-90:
- * cat([x[src], x[dest], edge_attr])).  Either output may be NULL. */
+ * cat([x[src], x[dest], edge_attr])).  Either output may be NULL.
+ * The tables are engine-internal gather tables for cgnn_edge_block; their element
+ * type follows `precision`: CGNN_F32 -> float32 row-major [n,H]; CGNN_BF16 -> bf16,
+ * 2*H bytes per row, the H values of a row stored half-split as [h][t][g][c] for
+ * feature 32t + 8g + 4h + c (each lane of the edge kernel reads one contiguous run). */
 int cgnn_project_nodes(const cgnn_linear* ws, const cgnn_linear* wd, int32_t precision,
-                       const float* x, int64_t n, float* ps, float* pd, void* stream);
+                       const float* x, int64_t n, void* ps, void* pd, void* stream);
 
 /* ---- K5+K6+K9: fused edge update ---------------------------------------------
  * For every edge e = (src[e] -> dst[e]):
@@ -99,8 +120,10 @@ int cgnn_project_nodes(const cgnn_linear* ws, const cgnn_linear* wd, int32_t pre
  *   e_out[e] = e_in[e] + u  (residual != 0, graph_network.py:182)  or  u
  *   e_upd[e] = u            (if e_upd != NULL; feeds message_source="edge")
  * with the first layer evaluated as ps[src] + pd[dst] + e_in * We^T.
- * mlp->layer[0] holds We (in_dim = D); e_out may alias e_in. */
-int cgnn_edge_block(const cgnn_mlp* mlp, const float* ps, const float* pd,
+ * mlp->layer[0] holds We (in_dim = D); e_out may alias e_in.
+ * e_in / e_out / e_upd are CGNN_TILED32 buffers of cgnn_tiled_rows(num_edges) rows;
+ * ps / pd are cgnn_project_nodes tables of the same precision as `mlp`. */
+int cgnn_edge_block(const cgnn_mlp* mlp, const void* ps, const void* pd,
                     const int32_t* src, const int32_t* dst, int64_t num_edges,
                     const float* e_in, float* e_out, float* e_upd, int32_t residual,
                     int32_t latent, void* stream);
@@ -112,8 +135,10 @@ int cgnn_edge_block(const cgnn_mlp* mlp, const float* ps, const float* pd,
  *    gather-sum, no atomics, bit-reproducible; dst is ignored (may be NULL).
  *  - fixed_k == 0: general edge list: out is zeroed, then run-length-reduced
  *    float atomics keyed by dst (sum order not reproducible).
+ * table_layout: CGNN_ROWS, or CGNN_TILED32 for per-edge messages (gather == NULL) straight from
+ * cgnn_edge_block's e_upd.  out is CGNN_ROWS.
  * reference graph_network.py:92 -> torch_geometric MessagePassing.propagate. */
-int cgnn_aggregate(const float* table, const int32_t* gather, const int32_t* dst,
+int cgnn_aggregate(const float* table, int32_t table_layout, const int32_t* gather, const int32_t* dst,
                    int64_t num_edges, int32_t fixed_k, int64_t num_nodes, int32_t width,
                    float* out, void* stream);
 

@@ -1,0 +1,53 @@
+"""Developer tool for profiling: run ONE op a few times at a given size (so that a rocprofv3 --pmc pass
+attributes counters to that kernel only).  python scripts/run_one_op.py edge_block --particles 1000000"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cosmology_gnn_simulation_amd import data_utils, graph_network, ops, synthetic  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("op", choices=["edge_block", "aggregate", "node_block", "project_nodes", "enc_edge", "knn"])
+ap.add_argument("--particles", type=int, default=1_000_000)
+ap.add_argument("--neighbors", type=int, default=16)
+ap.add_argument("--latent", type=int, default=128)
+ap.add_argument("--edge-precision", default="bf16")
+ap.add_argument("--node-precision", default="fp32")
+ap.add_argument("--iters", type=int, default=3)
+a = ap.parse_args()
+dev = "cuda"
+n, k, d = a.particles, a.neighbors, a.latent
+gen = torch.Generator(device=dev).manual_seed(0)
+if a.op == "knn":
+    pos = torch.rand(n, 3, device=dev, generator=gen)
+m = graph_network.EncodeProcessDecode(d, d, 2, 1, 3)
+m.load_state_dict(synthetic.make_state_dict(d, d, 2, 1, 3))
+m = m.to(dev).eval()
+m.edge_precision, m.node_precision = a.edge_precision, a.node_precision
+# synthetic spatially-local graph (no k-NN build under the profiler): senders within +-4096 rows of the receiver
+fk = k
+dst = torch.arange(n, device=dev, dtype=torch.int32).repeat_interleave(k)
+src = ((dst.long() + torch.randint(-4096, 4097, (n * k,), device=dev, generator=gen)) % n).to(torch.int32)
+P = m._pack(17, 4)
+p = P["rounds"][0]
+x = torch.randn(n, d, device=dev, generator=gen)
+e = ops.TiledRows.from_rows(torch.randn(n * k, d, device=dev, generator=gen))
+ea = torch.randn(n * k, 4, device=dev, generator=gen)
+ps, pd = ops.project_nodes(p.ws, p.wd, x)
+agg = ops.aggregate(x, src, dst, n, fk)
+fn = {
+    "edge_block": lambda: ops.edge_block(p.edge, ps, pd, src, dst, e, e, None, True),
+    "aggregate": lambda: ops.aggregate(x, src, dst, n, fk, n * k, agg),
+    "node_block": lambda: ops.node_block(p.node, p.wx, p.wa, x, agg, x, True),
+    "project_nodes": lambda: ops.project_nodes(p.ws, p.wd, x, ps, pd),
+    "enc_edge": lambda: ops.mlp_rows(P["enc_edge"], ea, out=e),
+    "knn": lambda: ops.knn_periodic(pos, 1.0, k),
+}[a.op]
+torch.cuda.synchronize()
+for _ in range(a.iters):
+    fn()
+torch.cuda.synchronize()
+print("done", a.op)

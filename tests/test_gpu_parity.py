@@ -144,6 +144,36 @@ def test_gather_scatter_rows():
     assert torch.equal(ops.gather_rows(t3.to(DEV), idx[:9].to(DEV) % 50).cpu(), t3[(idx[:9] % 50).long()])
 
 
+@pytest.mark.parametrize("n,width", [(1, 32), (1000, 64), (4097, 128), (33, 256)])
+def test_tiled_layout_roundtrip(n, width):
+    x = torch.randn(n, width, generator=torch.Generator().manual_seed(n))
+    t = ops.TiledRows.from_rows(x.to(DEV))
+    assert t.buf.shape[0] == ((n + 31) // 32) * 32
+    assert torch.equal(t.to_rows().cpu(), x)                       # pure data movement: bit exact
+    # the documented address map (include/cgnn.h): element (row, f) of tile T
+    row, f = n - 1, width - 3
+    T, r = divmod(row, 32)
+    tt, rem = divmod(f, 32)
+    g, rem = divmod(rem, 8)
+    h, c = divmod(rem, 4)
+    off = T * 32 * width + ((4 * tt + g) * 64 + 32 * h + r) * 4 + c
+    assert t.buf.view(-1)[off].item() == x[row, f].item()
+
+
+@pytest.mark.parametrize("n,k,width", [(77, 13, 32), (500, 16, 128), (64, 8, 64), (9, 32, 256)])
+def test_aggregate_tiled_messages(n, k, width):
+    gen = torch.Generator().manual_seed(k)
+    msg = torch.randn(n * k, width, generator=gen)
+    dst = torch.arange(n).repeat_interleave(k)
+    t = ops.TiledRows.from_rows(msg.to(DEV))
+    want = msg.view(n, k, width)[:, 0].clone()
+    for j in range(1, k):
+        want += msg.view(n, k, width)[:, j]
+    assert torch.equal(ops.aggregate(t, None, None, n, fixed_k=k).cpu(), want)
+    got = ops.aggregate(t, None, dst.to(DEV), n, fixed_k=0).cpu()          # general path on the tiled table
+    assert torch.allclose(got, want, rtol=0, atol=1e-5 * float(want.abs().max()))
+
+
 # ------------------------------------------------------------------ blocks and model vs golden
 @pytest.mark.parametrize("prec,tol_x,tol_e", [("fp32", TOL, TOL), ("bf16", 3e-2, 3e-2)])
 def test_interaction_block_vs_reference_fixture(golden_tiny, prec, tol_x, tol_e):
