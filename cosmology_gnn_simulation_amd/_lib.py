@@ -16,8 +16,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcgnn_hip.so")
 
 MAX_HIDDEN_LAYERS = 6
-F32, BF16 = 0, 1
-PRECISIONS = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}
+F32, BF16, BF16_N16 = 0, 1, 2          # cgnn_precision
+P_F32, P_BF16_S32, P_BF16_S16 = 0, 1, 2  # cgnn_ptable
+LDS_WEIGHT_BUDGET = 152 * 1024           # CGNN_LDS_WEIGHT_BUDGET in csrc/mlp_device.hpp
+PRECISIONS = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "bf16_n16": BF16_N16}
 
 # every symbol include/cgnn.h declares (tests check the library exports all of them)
 EXPORTS = (
@@ -68,7 +70,7 @@ def load() -> C.CDLL:
     lib.cgnn_tiled_rows.restype = i64
     lib.cgnn_tiled_rows.argtypes = [i64]
     lib.cgnn_relayout.argtypes = [vp, i32, vp, i32, i64, i32, vp]
-    lib.cgnn_project_nodes.argtypes = [C.POINTER(Linear), C.POINTER(Linear), i32, vp, i64, vp, vp, vp]
+    lib.cgnn_project_nodes.argtypes = [C.POINTER(Linear), C.POINTER(Linear), i32, vp, i64, vp, vp, i32, vp]
     lib.cgnn_edge_block.argtypes = [C.POINTER(Mlp), vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, vp]
     lib.cgnn_aggregate.argtypes = [vp, i32, vp, vp, i64, i32, i64, i32, vp, vp]
     lib.cgnn_node_block.argtypes = [C.POINTER(Mlp), C.POINTER(Linear), C.POINTER(Linear), vp, vp, i64, vp, i32, i32, vp]

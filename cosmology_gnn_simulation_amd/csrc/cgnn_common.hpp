@@ -366,6 +366,23 @@ struct PRow<CGNN_BF16> {
     }
 };
 
+// CGNN_P_BF16_S16 rows written from the 32-row act layout (the projection kernel keeps 32-row tiles): lane (r, h)
+// holds features 32t + 8g + 4h + c, which is 16-tile O = 2t + (g >> 1), quarter q = 2 (g & 1) + h, element c.
+template <int HT>
+__device__ __forceinline__ void store_prow_s16(const f32x16 (&acc)[HT], __bf16* __restrict__ base, int64_t row, int h) {
+    __bf16* rp = base + row * (32 * HT);
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int O = 2 * t + (g >> 1), q = 2 * (g & 1) + h;
+            bf16x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = (__bf16)acc[t][4 * g + c];
+            *reinterpret_cast<bf16x4*>(rp + q * (8 * HT) + 4 * O) = v;
+        }
+}
+
 // Ragged width (dim not a multiple of 32, or unaligned rows): scalar, zero padded.
 template <int T>
 __device__ __forceinline__ void load_rows_ragged(f32x16 (&a)[T], const float* __restrict__ rowp, int dim, int h) {

@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include "mlp_device.hpp"
+#include "n16.hpp"
 
 namespace cgnn {
 
@@ -121,6 +122,73 @@ static int launch_edge_lds(const MlpDev& m, size_t lds, const __bf16* ps, const 
     return check_hip(hipGetLastError(), "cgnn_edge_block(lds) launch");
 }
 
+// N16 variant (weights packed CGNN_BF16_N16, P tables CGNN_P_BF16_S16): 16 edges per wave, see n16.hpp.  The
+// f32 tile is read once, kept in registers for the residual, and written once.
+template <int HT, int DT>
+__global__ __launch_bounds__(CGNN_EDGE_LDS_BLOCK) void edge_block_n16_kernel(
+    MlpDev m, const __bf16* __restrict__ ps, const __bf16* __restrict__ pd, const int32_t* __restrict__ src,
+    const int32_t* __restrict__ dst, int64_t num_edges, const float* e_in, float* e_out, float* e_upd, int residual) {
+    stage_weights_to_lds(m, 0);
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    constexpr int D = 32 * DT, DO = 2 * DT, HO = 2 * HT;     // DO / HO: 16-feature tiles
+    const int64_t tiles = (num_edges + 15) / 16;
+    const TileRange tr = tile_range(tiles);
+    for (int64_t tile = tr.first; tile < tr.end; tile += tr.stride) {
+        const int64_t e = tile * 16 + c;
+        const int64_t ec = e < num_edges ? e : num_edges - 1;
+        const int64_t s = src[ec], d = dst[ec];
+        const int64_t tbase = (tile >> 1) * (32 * D) + n16_lane_offset(c, q, (int)(tile & 1));
+        f32x4 ev[DO];
+#pragma unroll
+        for (int o = 0; o < DO; ++o) ev[o] = *reinterpret_cast<const f32x4*>(e_in + tbase + n16_tile_offset(o));
+        bf16x8 oph[HT];
+        {
+            bf16x8 op[DT];
+            operand16<false, DT>(op, ev);
+            f32x4 acc[HO];
+            load_p16<HO, false>(acc, ps, s, q);
+            load_p16<HO, true>(acc, pd, d, q);
+            dense16<DT, HO>(acc, op, WSel<CGNN_BF16, true>::get(m, 0), lane);
+            operand16<true, HT>(oph, acc);
+        }
+        for (int l = 1; l < m.nh; ++l) {
+            f32x4 acc[HO];
+            fill16<HO>(acc, VecSel<true>::bias(m, l), q);
+            dense16<HT, HO>(acc, oph, WSel<CGNN_BF16, true>::get(m, l), lane);
+            operand16<true, HT>(oph, acc);
+        }
+        f32x4 out[DO];
+        fill16<DO>(out, VecSel<true>::bias(m, m.nh), q);
+        dense16<HT, DO>(out, oph, WSel<CGNN_BF16, true>::get(m, m.nh), lane);
+        layer_norm16<DO>(out, VecSel<true>::gamma(m), VecSel<true>::beta(m), q);
+        if (e_upd != nullptr) {
+#pragma unroll
+            for (int o = 0; o < DO; ++o) *reinterpret_cast<f32x4*>(e_upd + tbase + n16_tile_offset(o)) = out[o];
+        }
+#pragma unroll
+        for (int o = 0; o < DO; ++o) {
+            if (residual) out[o] += ev[o];
+            *reinterpret_cast<f32x4*>(e_out + tbase + n16_tile_offset(o)) = out[o];
+        }
+    }
+}
+
+template <int HT, int DT>
+static int launch_edge_n16(const MlpDev& m, size_t lds, const __bf16* ps, const __bf16* pd, const int32_t* src,
+                           const int32_t* dst, int64_t num_edges, const float* e_in, float* e_out, float* e_upd,
+                           int residual, hipStream_t st) {
+    auto kern = edge_block_n16_kernel<HT, DT>;
+    if (lds > 48 * 1024) {
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                           "hipFuncSetAttribute(edge_block_n16)");
+        if (rc != CGNN_OK) return rc;
+    }
+    const int grid = grid_for_tiles((num_edges + 15) / 16, 1, CGNN_EDGE_LDS_BLOCK / 64);
+    kern<<<grid, CGNN_EDGE_LDS_BLOCK, lds, st>>>(m, ps, pd, src, dst, num_edges, e_in, e_out, e_upd, residual);
+    return check_hip(hipGetLastError(), "cgnn_edge_block(n16) launch");
+}
+
 template <int PREC, bool WLDS, int HT, int DT>
 static int launch_edge(const MlpDev& m, size_t lds, const typename PRow<PREC>::elem* ps,
                        const typename PRow<PREC>::elem* pd, const int32_t* src,
@@ -174,6 +242,19 @@ extern "C" int cgnn_edge_block(const cgnn_mlp* mlp, const void* ps, const void* 
     if (num_edges == 0) return CGNN_OK;
     hipStream_t st = (hipStream_t)stream;
     const int HT = hidden / 32, DT = latent / 32, prec = mlp->precision;
+    if (prec == CGNN_BF16_N16) {
+        if (lds > CGNN_LDS_WEIGHT_BUDGET) {
+            set_error("cgnn_edge_block: CGNN_BF16_N16 needs the weights (%zu bytes) resident in LDS", lds);
+            return CGNN_ERR_UNSUPPORTED;
+        }
+#define CGNN_N16(Hh, Dd)      \
+    if (HT == Hh && DT == Dd) \
+        return launch_edge_n16<Hh, Dd>(m, lds, (const __bf16*)ps, (const __bf16*)pd, src, dst, num_edges, e_in, e_out, e_upd, residual, st);
+        CGNN_N16(1, 1) CGNN_N16(2, 2) CGNN_N16(4, 4) CGNN_N16(4, 2)
+#undef CGNN_N16
+        set_error("cgnn_edge_block: no CGNN_BF16_N16 kernel for latent=%d hidden=%d", latent, hidden);
+        return CGNN_ERR_UNSUPPORTED;
+    }
     const bool want_lds = prec == CGNN_BF16 && lds <= CGNN_LDS_WEIGHT_BUDGET && num_edges >= 4096;
 #define CGNN_PAIR(Hh, Dd)                                                                                        \
     if (HT == Hh && DT == Dd) {                                                                                   \

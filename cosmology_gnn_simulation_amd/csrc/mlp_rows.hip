@@ -51,11 +51,38 @@ __global__ __launch_bounds__(CGNN_BLOCK) void mlp_rows_kernel(MlpDev m, const fl
     }
 }
 
-template <int PREC, int DT, int HT>
+template <int PFMT>
+struct PFmt;
+template <>
+struct PFmt<CGNN_P_F32> {
+    typedef float elem;
+    template <int HT>
+    static __device__ __forceinline__ void store(const f32x16 (&a)[HT], float* b, int64_t row, int h) {
+        PRow<CGNN_F32>::store<HT>(a, b, row, h);
+    }
+};
+template <>
+struct PFmt<CGNN_P_BF16_S32> {
+    typedef __bf16 elem;
+    template <int HT>
+    static __device__ __forceinline__ void store(const f32x16 (&a)[HT], __bf16* b, int64_t row, int h) {
+        PRow<CGNN_BF16>::store<HT>(a, b, row, h);
+    }
+};
+template <>
+struct PFmt<CGNN_P_BF16_S16> {
+    typedef __bf16 elem;
+    template <int HT>
+    static __device__ __forceinline__ void store(const f32x16 (&a)[HT], __bf16* b, int64_t row, int h) {
+        store_prow_s16<HT>(a, b, row, h);
+    }
+};
+
+template <int PREC, int PFMT, int DT, int HT>
 __global__ __launch_bounds__(CGNN_BLOCK) void project_kernel(const void* ws, const void* wd, const float* __restrict__ bd,
                                                              int hidden, const float* __restrict__ x, int64_t n,
-                                                             typename PRow<PREC>::elem* __restrict__ ps,
-                                                             typename PRow<PREC>::elem* __restrict__ pd) {
+                                                             typename PFmt<PFMT>::elem* __restrict__ ps,
+                                                             typename PFmt<PFMT>::elem* __restrict__ pd) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int64_t tiles = (n + 31) / 32;
     constexpr unsigned wbytes = DT * HT * 1024 * (PREC == CGNN_BF16 ? 2 : 4);
@@ -74,13 +101,13 @@ __global__ __launch_bounds__(CGNN_BLOCK) void project_kernel(const void* ws, con
             f32x16 acc[HT];
             acc_fill_bias<HT>(acc, (const float*)nullptr, hidden, h);
             dense<DT, HT>(acc, op, wsrc_s, lane);
-            if (row < n) PRow<PREC>::template store<HT>(acc, ps, row, h);
+            if (row < n) PFmt<PFMT>::template store<HT>(acc, ps, row, h);
         }
         if (pd != nullptr) {
             f32x16 acc[HT];
             acc_fill_bias<HT>(acc, bd, hidden, h);
             dense<DT, HT>(acc, op, wsrc_d, lane);
-            if (row < n) PRow<PREC>::template store<HT>(acc, pd, row, h);
+            if (row < n) PFmt<PFMT>::template store<HT>(acc, pd, row, h);
         }
     }
 }
@@ -174,7 +201,7 @@ int cgnn_mlp_rows(const cgnn_mlp* mlp, const float* x, int64_t n, int32_t ld_x, 
 }
 
 int cgnn_project_nodes(const cgnn_linear* ws, const cgnn_linear* wd, int32_t precision, const float* x, int64_t n,
-                       void* ps, void* pd, void* stream) {
+                       void* ps, void* pd, int32_t p_format, void* stream) {
     if (!x || n < 0 || (!ps && !pd) || (ps && (!ws || !ws->w)) || (pd && (!wd || !wd->w))) {
         set_error("cgnn_project_nodes: invalid argument");
         return CGNN_ERR_INVALID_ARG;
@@ -196,19 +223,24 @@ int cgnn_project_nodes(const cgnn_linear* ws, const cgnn_linear* wd, int32_t pre
     const void* wsp = ps ? ws->w : nullptr;
     const void* wdp = pd ? wd->w : nullptr;
     const float* bd = pd ? wd->b : nullptr;
-#define CGNN_PAIR(Hh, Dd)                                                                                       \
-    if (HT == Hh && DT == Dd) {                                                                                  \
-        if (precision == CGNN_F32)                                                                               \
-            project_kernel<CGNN_F32, Dd, Hh><<<grid, CGNN_BLOCK, 0, st>>>(wsp, wdp, bd, H, x, n, (float*)ps,     \
-                                                                          (float*)pd);                           \
-        else if (precision == CGNN_BF16)                                                                         \
-            project_kernel<CGNN_BF16, Dd, Hh><<<grid, CGNN_BLOCK, 0, st>>>(wsp, wdp, bd, H, x, n, (__bf16*)ps,   \
-                                                                           (__bf16*)pd);                         \
-        else {                                                                                                   \
-            set_error("cgnn_project_nodes: unknown precision %d", precision);                                    \
-            return CGNN_ERR_INVALID_ARG;                                                                         \
-        }                                                                                                        \
-        return check_hip(hipGetLastError(), "cgnn_project_nodes launch");                                        \
+    if ((precision == CGNN_F32) != (p_format == CGNN_P_F32) ||
+        (precision != CGNN_F32 && precision != CGNN_BF16) ||
+        (p_format != CGNN_P_F32 && p_format != CGNN_P_BF16_S32 && p_format != CGNN_P_BF16_S16)) {
+        set_error("cgnn_project_nodes: precision %d / p_format %d combination is not supported", precision, p_format);
+        return CGNN_ERR_INVALID_ARG;
+    }
+#define CGNN_PAIR(Hh, Dd)                                                                                          \
+    if (HT == Hh && DT == Dd) {                                                                                     \
+        if (p_format == CGNN_P_F32)                                                                                 \
+            project_kernel<CGNN_F32, CGNN_P_F32, Dd, Hh><<<grid, CGNN_BLOCK, 0, st>>>(wsp, wdp, bd, H, x, n,         \
+                                                                                     (float*)ps, (float*)pd);      \
+        else if (p_format == CGNN_P_BF16_S32)                                                                       \
+            project_kernel<CGNN_BF16, CGNN_P_BF16_S32, Dd, Hh><<<grid, CGNN_BLOCK, 0, st>>>(                         \
+                wsp, wdp, bd, H, x, n, (__bf16*)ps, (__bf16*)pd);                                                   \
+        else                                                                                                        \
+            project_kernel<CGNN_BF16, CGNN_P_BF16_S16, Dd, Hh><<<grid, CGNN_BLOCK, 0, st>>>(                         \
+                wsp, wdp, bd, H, x, n, (__bf16*)ps, (__bf16*)pd);                                                   \
+        return check_hip(hipGetLastError(), "cgnn_project_nodes launch");                                           \
     }
     CGNN_FOR_EACH_PAIR(CGNN_PAIR)
 #undef CGNN_PAIR

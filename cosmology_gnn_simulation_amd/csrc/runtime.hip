@@ -78,6 +78,23 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, int out_dim, int l
     wp[idx] = (__bf16)v;
 }
 
+// CGNN_BF16_N16: fragment m = O * KS + s (16-feature out tile O, 32-wide k-step s), A[row][k] of
+// v_mfma_f32_16x16x32_bf16: lane l holds row l & 15, k = 8 (l >> 4) + j  <->  feature phi(s, l >> 4, j) (n16.hpp)
+__global__ void pack_bf16_n16_kernel(const float* __restrict__ w, int out_dim, int ld, int col0, int ncols, int KS,
+                                     int64_t total, __bf16* __restrict__ wp) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int j = (int)(idx & 7);
+    const int l = (int)((idx >> 3) & 63);
+    const int64_t m = idx >> 9;
+    const int s = (int)(m % KS);
+    const int o = (int)(m / KS);
+    const int row = 16 * o + (l & 15);
+    const int k = 32 * s + 16 * (j >> 2) + 4 * (l >> 4) + (j & 3);
+    const float v = (row < out_dim && k < ncols) ? w[(int64_t)row * ld + col0 + k] : 0.f;
+    wp[idx] = (__bf16)v;
+}
+
 // ------------------------------------------------------------------ aggregation
 // Fixed in-degree, receiver-sorted: one (row, 16-byte chunk) per thread; the k
 // neighbour rows are read with 16 B per lane, a row's chunks on adjacent lanes.
@@ -273,7 +290,9 @@ const char* cgnn_last_error(void) { return g_err; }
 
 size_t cgnn_packed_linear_bytes(int32_t out_dim, int32_t ncols, int32_t precision) {
     if (out_dim <= 0 || ncols <= 0) return 0;
-    const size_t ot = (size_t)(out_dim + 31) / 32, kt = (size_t)(ncols + 31) / 32;
+    const size_t kt = (size_t)(ncols + 31) / 32;
+    if (precision == CGNN_BF16_N16) return (size_t)((out_dim + 15) / 16) * kt * 1024;
+    const size_t ot = (size_t)(out_dim + 31) / 32;
     return ot * kt * 1024 * (precision == CGNN_BF16 ? 2 : 4);
 }
 
@@ -284,9 +303,15 @@ int cgnn_pack_linear(const float* w, int32_t out_dim, int32_t ld, int32_t col0, 
         return CGNN_ERR_INVALID_ARG;
     }
     const int OT = (out_dim + 31) / 32, KT = (ncols + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    if (precision == CGNN_BF16_N16) {
+        const int64_t tot16 = (int64_t)((out_dim + 15) / 16) * KT * 512;
+        pack_bf16_n16_kernel<<<(unsigned)((tot16 + CGNN_BLOCK - 1) / CGNN_BLOCK), CGNN_BLOCK, 0, st>>>(
+            w, out_dim, ld, col0, ncols, KT, tot16, (__bf16*)packed);
+        return check_hip(hipGetLastError(), "cgnn_pack_linear launch");
+    }
     const int64_t total = (int64_t)OT * KT * 1024;
     const int blocks = (int)((total + CGNN_BLOCK - 1) / CGNN_BLOCK);
-    hipStream_t st = (hipStream_t)stream;
     if (precision == CGNN_F32)
         pack_f32_kernel<<<blocks, CGNN_BLOCK, 0, st>>>(w, out_dim, ld, col0, ncols, KT, total, (float*)packed);
     else if (precision == CGNN_BF16)

@@ -197,7 +197,7 @@ class ShardedForward:
         key = (D, H, dev, self.model.edge_precision)
         if self._bufs is None or self._bufs[0] != key:
             x_all = torch.empty((sh.n_local, D), dtype=torch.float32, device=dev)
-            pdt = ops.p_table_dtype(self.model.edge_precision)
+            pdt = self.P["rounds"][0].p_dtype if self.P["rounds"] else torch.float32
             ps = torch.empty((sh.n_local, H), dtype=pdt, device=dev)
             pd = torch.empty((sh.n_owned, H), dtype=pdt, device=dev)
             agg = torch.empty((sh.n_owned, D), dtype=torch.float32, device=dev)
@@ -220,8 +220,8 @@ class ShardedForward:
         m, sh = self.model, self.sh
         p = self.P["rounds"][i]
         x_own = self.x_all[:sh.n_owned]
-        ops.project_nodes(p.ws, None, self.x_all, self.ps, None)        # senders may be ghosts
-        ops.project_nodes(None, p.wd, x_own, None, self.pd)             # receivers are owned
+        ops.project_nodes(p.ws, None, self.x_all, self.ps, None, p.p_format)    # senders may be ghosts
+        ops.project_nodes(None, p.wd, x_own, None, self.pd, p.p_format)         # receivers are owned
         edge_mode = m.message_source == "edge"
         ops.edge_block(p.edge, self.ps, self.pd, sh.src_local, sh.dst_local, self.el, self.el,
                        self.e_upd if edge_mode else None, True)

@@ -26,7 +26,7 @@ from typing import List, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from ._lib import CgnnError, require_device
 from .graph import Data
 
@@ -226,6 +226,12 @@ class _PackedProcessor:
         self.ws = ops.PackedLinear(w1e, None, edge_precision, 0, D)
         self.wd = ops.PackedLinear(w1e, b1e, edge_precision, D, D)
         self.edge = _pack_mlp(net.edge_model, edge_precision, first_layer_cols=(2 * D, D))
+        if self.edge.precision == _lib.BF16 and D <= 128 and self.edge.hidden <= 128 and \
+                self.edge.lds_bytes() <= _lib.LDS_WEIGHT_BUDGET:
+            # weights fit in LDS: use the 16-edge-per-wave kernel (its own packing + P-table format)
+            self.edge = _pack_mlp(net.edge_model, "bf16_n16", first_layer_cols=(2 * D, D))
+        self.p_format = ops.p_table_format(self.edge.precision)
+        self.p_dtype = ops.p_table_dtype(self.edge.precision)
         # cat([x, aggregated]) -> [Wx | Wa]                         (reference graph_network.py:94)
         self.wx = ops.PackedLinear(w1n, b1n, node_precision, 0, D)
         self.wa = ops.PackedLinear(w1n, None, node_precision, D, D)
@@ -239,7 +245,7 @@ def _run_round(p: _PackedProcessor, x: torch.Tensor, e: torch.Tensor, src, dst, 
     ps = pd = agg = e_upd = None
     if scratch is not None:
         ps, pd, agg, e_upd = scratch
-    ps, pd = ops.project_nodes(p.ws, p.wd, x, ps, pd)
+    ps, pd = ops.project_nodes(p.ws, p.wd, x, ps, pd, p.p_format)
     if message_source == "edge" and e_upd is None:
         e_upd = e.empty_like()
     e_new = ops.edge_block(p.edge, ps, pd, src, dst, e, e_out, e_upd if message_source == "edge" else None, residual)
@@ -400,7 +406,7 @@ class EncodeProcessDecode(nn.Module):
             scratch = None
             if P["rounds"]:
                 dev = x.device
-                pdt = ops.p_table_dtype(self.edge_precision)
+                pdt = P["rounds"][0].p_dtype
                 ps = torch.empty((n, H), dtype=pdt, device=dev)
                 pd = torch.empty((n, H), dtype=pdt, device=dev)
                 agg = torch.empty((n, xl.shape[1]), dtype=torch.float32, device=dev)

@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, CgnnError, Linear, Mlp, check, f32c, i32c, ptr, require_device, stream_ptr
+from ._lib import BF16, BF16_N16, F32, CgnnError, Linear, Mlp, check, f32c, i32c, ptr, require_device, stream_ptr
 
 
 # ---- optional per-op timing with HIP events on the launch stream (bench.py) -------------------------------
@@ -124,6 +124,12 @@ class PackedMLP:
     def struct(self) -> Mlp:
         return self._struct
 
+    def lds_bytes(self) -> int:
+        """Bytes the LDS-resident kernels need for this MLP (packed weights + bias / LayerNorm vectors)."""
+        pad16 = lambda n: (n * 4 + 15) // 16 * 16  # noqa: E731
+        return sum(L.packed.numel() for L in self.layers) + sum(pad16(L.out_dim) for L in self.layers) + \
+            2 * pad16(self.out_dim)
+
 
 class TiledRows:
     """An ``[n, width]`` float32 matrix in the engine's TILED32 layout (``cgnn_layout`` in include/cgnn.h):
@@ -189,17 +195,27 @@ def mlp_rows(mlp: PackedMLP, x: torch.Tensor, out=None, tiled: bool = False):
     return y
 
 
-def p_table_dtype(precision) -> torch.dtype:
+def p_table_format(edge_mlp_precision) -> int:
+    """``cgnn_ptable`` format the edge kernel of this precision gathers from (include/cgnn.h)."""
+    return {F32: _lib.P_F32, BF16: _lib.P_BF16_S32, BF16_N16: _lib.P_BF16_S16}[_prec(edge_mlp_precision)]
+
+
+def p_table_dtype(edge_mlp_precision) -> torch.dtype:
     """Element type of the Ps/Pd gather tables (engine-internal layout, see include/cgnn.h)."""
-    return torch.bfloat16 if _prec(precision) == BF16 else torch.float32
+    return torch.float32 if _prec(edge_mlp_precision) == F32 else torch.bfloat16
 
 
 def project_nodes(ws: Optional[PackedLinear], wd: Optional[PackedLinear], x: torch.Tensor,
-                  ps: Optional[torch.Tensor] = None, pd: Optional[torch.Tensor] = None):
+                  ps: Optional[torch.Tensor] = None, pd: Optional[torch.Tensor] = None,
+                  p_format: Optional[int] = None):
+    """Per-node halves of the edge model's first Linear.  ``p_format`` (``cgnn_ptable``) defaults to the format
+    the edge kernel of the weights' own precision expects."""
     x = f32c(x, "x")
     n = x.shape[0]
     ref = ws if ws is not None else wd
-    pdt = p_table_dtype(ref.precision)
+    if p_format is None:
+        p_format = p_table_format(ref.precision)
+    pdt = torch.float32 if p_format == _lib.P_F32 else torch.bfloat16
     if ws is not None and ps is None:
         ps = torch.empty((n, ws.out_dim), dtype=pdt, device=x.device)
     if wd is not None and pd is None:
@@ -213,7 +229,7 @@ def project_nodes(ws: Optional[PackedLinear], wd: Optional[PackedLinear], x: tor
         check(_lib.load().cgnn_project_nodes(C.byref(s1) if s1 is not None else None,
                                          C.byref(s2) if s2 is not None else None, ref.precision, x.data_ptr(), n,
                                          ptr(ps) if ws is not None else None, ptr(pd) if wd is not None else None,
-                                         stream_ptr(x.device)), "cgnn_project_nodes")
+                                         p_format, stream_ptr(x.device)), "cgnn_project_nodes")
     return ps, pd
 
 

@@ -41,9 +41,19 @@ typedef enum {
 } cgnn_status;
 
 typedef enum {
-    CGNN_F32 = 0,   /* f32 operands, v_mfma_f32_32x32x2_f32, exact f32 (parity mode) */
-    CGNN_BF16 = 1   /* bf16 operands, v_mfma_f32_32x32x16_bf16, f32 accumulate       */
+    CGNN_F32 = 0,      /* f32 operands, v_mfma_f32_32x32x2_f32, exact f32 (parity mode)     */
+    CGNN_BF16 = 1,     /* bf16 operands, v_mfma_f32_32x32x16_bf16, f32 accumulate           */
+    CGNN_BF16_N16 = 2  /* same arithmetic as CGNN_BF16, weights packed for the 16-edge-per-
+                          wave kernel (v_mfma_f32_16x16x32_bf16); cgnn_edge_block only      */
 } cgnn_precision;
+
+/* Element type / row order of the Ps, Pd gather tables (cgnn_project_nodes -> cgnn_edge_block).
+ * Feature f of a row of H values:
+ *   CGNN_P_F32       float32, position f                                  (mlp precision CGNN_F32)
+ *   CGNN_P_BF16_S32  bf16, f = 32t+8g+4h+c at h*(H/2) + (4t+g)*4 + c      (mlp precision CGNN_BF16)
+ *   CGNN_P_BF16_S16  bf16, f = 16O+4q+i    at q*(H/4) + 4*O + i           (mlp precision CGNN_BF16_N16)
+ * i.e. each lane of the consuming kernel reads one contiguous run. */
+typedef enum { CGNN_P_F32 = 0, CGNN_P_BF16_S32 = 1, CGNN_P_BF16_S16 = 2 } cgnn_ptable;
 
 /*
  * Memory layout of an [n, width] float32 matrix.
@@ -107,12 +117,10 @@ int cgnn_relayout(const float* src, int32_t from, float* dst, int32_t to, int64_
  * ps[n,H] = x[n,D] * Ws^T ; pd[n,H] = x[n,D] * Wd^T + b1, where [Ws|Wd|We] is the
  * column split of the edge model's first Linear (reference graph_network.py:89-90:
  * cat([x[src], x[dest], edge_attr])).  Either output may be NULL.
- * The tables are engine-internal gather tables for cgnn_edge_block; their element
- * type follows `precision`: CGNN_F32 -> float32 row-major [n,H]; CGNN_BF16 -> bf16,
- * 2*H bytes per row, the H values of a row stored half-split as [h][t][g][c] for
- * feature 32t + 8g + 4h + c (each lane of the edge kernel reads one contiguous run). */
+ * `precision` is the packing of ws/wd (CGNN_F32 or CGNN_BF16); `p_format` (cgnn_ptable)
+ * the layout of the tables, which must be the one the consuming cgnn_edge_block expects. */
 int cgnn_project_nodes(const cgnn_linear* ws, const cgnn_linear* wd, int32_t precision,
-                       const float* x, int64_t n, void* ps, void* pd, void* stream);
+                       const float* x, int64_t n, void* ps, void* pd, int32_t p_format, void* stream);
 
 /* ---- K5+K6+K9: fused edge update ---------------------------------------------
  * For every edge e = (src[e] -> dst[e]):
@@ -122,7 +130,7 @@ int cgnn_project_nodes(const cgnn_linear* ws, const cgnn_linear* wd, int32_t pre
  * with the first layer evaluated as ps[src] + pd[dst] + e_in * We^T.
  * mlp->layer[0] holds We (in_dim = D); e_out may alias e_in.
  * e_in / e_out / e_upd are CGNN_TILED32 buffers of cgnn_tiled_rows(num_edges) rows;
- * ps / pd are cgnn_project_nodes tables of the same precision as `mlp`. */
+ * ps / pd are cgnn_project_nodes tables in the cgnn_ptable format matching mlp->precision. */
 int cgnn_edge_block(const cgnn_mlp* mlp, const void* ps, const void* pd,
                     const int32_t* src, const int32_t* dst, int64_t num_edges,
                     const float* e_in, float* e_out, float* e_upd, int32_t residual,

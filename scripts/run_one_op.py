@@ -36,13 +36,13 @@ p = P["rounds"][0]
 x = torch.randn(n, d, device=dev, generator=gen)
 e = ops.TiledRows.from_rows(torch.randn(n * k, d, device=dev, generator=gen))
 ea = torch.randn(n * k, 4, device=dev, generator=gen)
-ps, pd = ops.project_nodes(p.ws, p.wd, x)
+ps, pd = ops.project_nodes(p.ws, p.wd, x, None, None, p.p_format)
 agg = ops.aggregate(x, src, dst, n, fk)
 fn = {
     "edge_block": lambda: ops.edge_block(p.edge, ps, pd, src, dst, e, e, None, True),
     "aggregate": lambda: ops.aggregate(x, src, dst, n, fk, n * k, agg),
     "node_block": lambda: ops.node_block(p.node, p.wx, p.wa, x, agg, x, True),
-    "project_nodes": lambda: ops.project_nodes(p.ws, p.wd, x, ps, pd),
+    "project_nodes": lambda: ops.project_nodes(p.ws, p.wd, x, ps, pd, p.p_format),
     "enc_edge": lambda: ops.mlp_rows(P["enc_edge"], ea, out=e),
     "knn": lambda: ops.knn_periodic(pos, 1.0, k),
 }[a.op]

@@ -35,7 +35,7 @@ x = torch.randn(n, d, device=dev)
 e = ops.TiledRows.from_rows(torch.randn(n * k, d, device=dev))
 ea = torch.randn(n * k, 4, device=dev)
 xf = torch.randn(n, 17, device=dev)
-ps, pd = ops.project_nodes(p.ws, p.wd, x)
+ps, pd = ops.project_nodes(p.ws, p.wd, x, None, None, p.p_format)
 agg = ops.aggregate(x, src, dst, n, fk)
 
 
@@ -61,7 +61,7 @@ t("edge_block", lambda: ops.edge_block(p.edge, ps, pd, src, dst, e, e, None, Tru
   2 * E * d * 4 + 2 * E * 4 + 2 * n * d * 4, 6.0 * E * d * d)
 t("aggregate x_j", lambda: ops.aggregate(x, src, dst, n, fk, E, agg), E * d * 4 + E * 4 + n * d * 4)
 t("node_block", lambda: ops.node_block(p.node, p.wx, p.wa, x, agg, x, True), 3 * n * d * 4, 8.0 * n * d * d)
-t("project_nodes", lambda: ops.project_nodes(p.ws, p.wd, x, ps, pd), 3 * n * d * 4, 4.0 * n * d * d)
+t("project_nodes", lambda: ops.project_nodes(p.ws, p.wd, x, ps, pd, p.p_format), 3 * n * d * 4, 4.0 * n * d * d)
 t("enc_edge", lambda: ops.mlp_rows(P["enc_edge"], ea, out=e), E * (16 + d * 4), 2.0 * E * (32 * d + 2 * d * d))
 t("enc_node", lambda: ops.mlp_rows(P["enc_node"], xf, out=x), n * (68 + d * 4), 2.0 * n * (32 * d + 2 * d * d))
 t("dec_acc", lambda: ops.mlp_rows(P["dec_acc"], x), n * (d * 4 + 12), 2.0 * n * (2 * d * d + 32 * d))

@@ -174,6 +174,35 @@ def test_aggregate_tiled_messages(n, k, width):
     assert torch.allclose(got, want, rtol=0, atol=1e-5 * float(want.abs().max()))
 
 
+@pytest.mark.parametrize("fmt,tol", [("fp32", 2e-6), ("bf16", 3e-2), ("bf16_n16", 3e-2)])
+@pytest.mark.parametrize("n,k,d", [(300, 8, 32), (1000, 16, 128), (70, 5, 64)])
+def test_edge_block_kernel_variants(fmt, tol, n, k, d):
+    """Every edge-kernel variant (exact f32, 32-row bf16, 16-row bf16) against the oracle's edge update."""
+    gen = torch.Generator().manual_seed(n + d)
+    E = n * k
+    x = torch.randn(n, d, generator=gen)
+    e = torch.randn(E, d, generator=gen)
+    src = torch.randint(0, n, (E,), generator=gen)
+    dst = torch.arange(n).repeat_interleave(k)
+    sd = {"m.0.0.weight": (torch.rand(d, 3 * d, generator=gen) * 2 - 1) / (3 * d) ** 0.5, "m.0.0.bias": torch.rand(d, generator=gen) - 0.5,
+          "m.0.2.weight": (torch.rand(d, d, generator=gen) * 2 - 1) / d ** 0.5, "m.0.2.bias": torch.rand(d, generator=gen) - 0.5,
+          "m.0.4.weight": (torch.rand(d, d, generator=gen) * 2 - 1) / d ** 0.5, "m.0.4.bias": torch.rand(d, generator=gen) - 0.5,
+          "m.1.weight": 1 + 0.1 * torch.randn(d, generator=gen), "m.1.bias": 0.1 * torch.randn(d, generator=gen)}
+    want = e + cpu_ref.mlp_ln(sd, "m", torch.cat([x[src], x[dst], e], dim=-1), 2)
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    w1, b1 = dev(sd["m.0.0.weight"]), dev(sd["m.0.0.bias"])
+    lin = [(w1, b1), (dev(sd["m.0.2.weight"]), dev(sd["m.0.2.bias"])), (dev(sd["m.0.4.weight"]), dev(sd["m.0.4.bias"]))]
+    mlp = ops.PackedMLP(lin, (dev(sd["m.1.weight"]), dev(sd["m.1.bias"])), fmt, first_layer_cols=(2 * d, d))
+    wprec = "fp32" if fmt == "fp32" else "bf16"
+    ws, wd = ops.PackedLinear(w1, None, wprec, 0, d), ops.PackedLinear(w1, b1, wprec, d, d)
+    ps, pd = ops.project_nodes(ws, wd, dev(x), None, None, ops.p_table_format(mlp.precision))
+    et = ops.TiledRows.from_rows(dev(e))
+    upd = et.empty_like()
+    got = ops.edge_block(mlp, ps, pd, dev(src), dev(dst), et, None, upd, True)
+    assert rel_l2(got.to_rows().cpu(), want) <= tol
+    assert rel_l2((got.to_rows() - upd.to_rows()).cpu(), e) <= 1e-6      # e_out - e_upd == e_in (f32 residual)
+
+
 # ------------------------------------------------------------------ blocks and model vs golden
 @pytest.mark.parametrize("prec,tol_x,tol_e", [("fp32", TOL, TOL), ("bf16", 3e-2, 3e-2)])
 def test_interaction_block_vs_reference_fixture(golden_tiny, prec, tol_x, tol_e):
