@@ -53,6 +53,10 @@ def parse_args():
     p.add_argument("--cpu-particles", type=int, default=16384, help="bounded CPU-baseline sample size")
     p.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (box share)")
     p.add_argument("--seed", type=int, default=1236)   # 1234 + cfg index 2
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                   help="process-group backend for --gpus > 1 (gloo = single-GPU rehearsal, staged through the host)")
+    p.add_argument("--check", action="store_true",
+                   help="N > 1: also run the unsharded forward on rank 0 and compare (small sizes only)")
     return p.parse_args()
 
 
@@ -79,6 +83,25 @@ def cpu_baseline(args, dev_outputs=None):
                       f"({sec:.2f} s on {cores} host threads)"}
 
 
+def _check_against_unsharded(args, model, sharded, runner, dev, rank, world, meta, k):
+    """Every rank compares its owned rows with the unsharded forward of the same global box (bit-exact: each
+    receiver sums its senders in the same order)."""
+    import torch.distributed as dist
+    from cosmology_gnn_simulation_amd import data_utils, synthetic
+    snap = synthetic.make_snapshot(args.particles * world, seed=args.seed)
+    g = data_utils.preprocess(snap["Coordinates"][:5], snap["InternalEnergy"][:5], meta, None, None, 0.0, k,
+                              meta["dt"], meta["box_size"], device=dev)
+    with torch.no_grad():
+        want = model(g)
+        got = runner()
+    ok = all(torch.equal(got[key], want[key][sharded.owned_global]) for key in ("acceleration", "temp_rate"))
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN) if dist.get_backend() == "gloo" else None
+    print(f"[rank {rank}] sharded == unsharded on owned rows: {ok}", file=sys.stderr, flush=True)
+    if not ok:
+        raise SystemExit("sharded forward differs from the unsharded one")
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,6 +112,8 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    if args.backend == "gloo":          # rehearsal: every rank shares the visible GPU(s)
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -107,7 +132,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         from cosmology_gnn_simulation_amd import dist as cdist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
         dist_ctx = cdist
 
     # ---- synthetic input, resident in HBM before the timed region -----------------------------------
@@ -154,12 +182,15 @@ def main():
 
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        cdev = dev if args.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        cnt = torch.tensor([float(e_local)], device=dev, dtype=torch.float64)
+        cnt = torch.tensor([float(e_local)], device=cdev, dtype=torch.float64)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         e_total = int(cnt.item())
+        if args.check:
+            _check_against_unsharded(args, model, sharded, runner, dev, rank, world, meta, k)
     else:
         e_total = e_local
     ms_per_step = elapsed / args.steps * 1e3
@@ -177,6 +208,9 @@ def main():
         flops_exec = 2.0 * e_local * (d * h + (args.hidden_layers - 1) * h * h + h * d)
         flops_alg = 2.0 * e_local * (3 * d * h + (args.hidden_layers - 1) * h * h + h * d)
         mfma_peak = MFMA_BF16_PEAK_TFLOPS if args.edge_precision == "bf16" else MFMA_F32_PEAK_TFLOPS
+        n16 = args.edge_precision == "bf16" and d <= 128 and h <= 128
+        edge_kernel_name = (f"cgnn::edge_block_n16_kernel<{h // 32},{d // 32}>" if n16 else
+                            f"cgnn::edge_block_kernel<{args.edge_precision},{h // 32},{d // 32}>")
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.isfile(tpath):
@@ -184,7 +218,7 @@ def main():
                 traffic = json.load(open(tpath)).get(f"edge_block:{n_local}:{k}:{d}:{args.edge_precision}")
             except Exception:
                 traffic = None
-        roofline = {"kernel": "edge_block_kernel", "bound": "hbm", "achieved": round(achieved, 1),
+        roofline = {"kernel": edge_kernel_name, "bound": "hbm", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "avg_launch_ms": round(edge_ms, 4), "launches": calls,
                     "algorithmic_bytes_per_launch": alg_bytes,

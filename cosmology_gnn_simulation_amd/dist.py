@@ -139,18 +139,26 @@ def finish_shard(sh: Shard, requests_from_peers: Sequence[torch.Tensor]) -> Shar
     return sh
 
 
+def _comm_device(tensor_device: torch.device, group=None) -> torch.device:
+    """Device the process group moves data on: the tensors' own device with RCCL ("nccl"); the host with gloo
+    (CPU tests, and the single-GPU rehearsal of the multi-rank path, which stages through host memory)."""
+    import torch.distributed as dist
+    return tensor_device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
 def exchange_requests(sh: Shard, group=None) -> Shard:
     """Setup-time all-to-all of the ghost id lists (sizes, then ids)."""
     import torch.distributed as dist
     dev = sh.owned_global.device
-    counts_out = torch.tensor(sh.recv_counts, dtype=torch.int64, device=dev)
+    cdev = _comm_device(dev, group)
+    counts_out = torch.tensor(sh.recv_counts, dtype=torch.int64, device=cdev)
     counts_in = torch.empty_like(counts_out)
     dist.all_to_all_single(counts_in, counts_out, group=group)
     counts_in_l = counts_in.tolist()
-    recv = torch.empty(int(sum(counts_in_l)), dtype=torch.int64, device=dev)
-    dist.all_to_all_single(recv, sh.ghost_global.contiguous(), output_split_sizes=counts_in_l,
+    recv = torch.empty(int(sum(counts_in_l)), dtype=torch.int64, device=cdev)
+    dist.all_to_all_single(recv, sh.ghost_global.to(cdev).contiguous(), output_split_sizes=counts_in_l,
                            input_split_sizes=sh.recv_counts, group=group)
-    return finish_shard(sh, list(torch.split(recv, counts_in_l)))
+    return finish_shard(sh, [t.to(dev) for t in torch.split(recv, counts_in_l)])
 
 
 # ----------------------------------------------------------------------------
@@ -174,8 +182,15 @@ class HaloExchange:
         if sh.send_idx.numel():
             self.pack(table, sh.send_idx, self._buf)
         ghosts = table[sh.n_owned:]
-        dist.all_to_all_single(ghosts, self._buf, output_split_sizes=sh.recv_counts,
-                               input_split_sizes=sh.send_counts, group=self.group)
+        cdev = _comm_device(table.device, self.group)
+        if cdev == table.device:
+            dist.all_to_all_single(ghosts, self._buf, output_split_sizes=sh.recv_counts,
+                                   input_split_sizes=sh.send_counts, group=self.group)
+        else:  # gloo rehearsal with device tensors: stage through host memory
+            recv = torch.empty(ghosts.shape, dtype=ghosts.dtype, device=cdev)
+            dist.all_to_all_single(recv, self._buf.to(cdev), output_split_sizes=sh.recv_counts,
+                                   input_split_sizes=sh.send_counts, group=self.group)
+            ghosts.copy_(recv)
 
 
 # ----------------------------------------------------------------------------

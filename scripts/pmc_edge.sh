@@ -7,9 +7,7 @@ mkdir -p $OUT
 REPO=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 i=0
-for SET in "TCC_HIT TCC_MISS TCC_EA0_RDREQ TCC_EA0_WRREQ" \
-           "TA_TA_BUSY TA_TOTAL_WAVEFRONTS" \
-           "TCC_EA0_RDREQ_32B TCC_EA0_WRREQ_64B TCC_REQ TCC_READ"; do
+for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT TCC_MISS TCC_EA0_RDREQ TCC_EA0_WRREQ"; do
   i=$((i+1))
   echo "pass $i: $SET"
   timeout -k 5 240 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/p$i -- python3 $REPO/scripts/run_one_op.py $OP "${@:2}" > $OUT/p$i.log 2>&1 || echo "pass $i failed"

@@ -17,6 +17,7 @@ ap.add_argument("--latent", type=int, default=128)
 ap.add_argument("--edge-precision", default="bf16")
 ap.add_argument("--node-precision", default="fp32")
 ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--real-graph", action="store_true", help="build the periodic k-NN graph (slower under --pmc)")
 a = ap.parse_args()
 dev = "cuda"
 n, k, d = a.particles, a.neighbors, a.latent
@@ -29,8 +30,16 @@ m = m.to(dev).eval()
 m.edge_precision, m.node_precision = a.edge_precision, a.node_precision
 # synthetic spatially-local graph (no k-NN build under the profiler): senders within +-4096 rows of the receiver
 fk = k
-dst = torch.arange(n, device=dev, dtype=torch.int32).repeat_interleave(k)
-src = ((dst.long() + torch.randint(-4096, 4097, (n * k,), device=dev, generator=gen)) % n).to(torch.int32)
+if a.real_graph:
+    pos = torch.rand(n, 3, device=dev, generator=gen)
+    snd, _, order = ops.knn_periodic(pos, 1.0, k, want_edge_attr=False, want_order=True)
+    g = graph_network.Data(edge_index=torch.stack([snd.long(), torch.arange(n, device=dev).repeat_interleave(k)]))
+    g._cgnn_order, g._cgnn_fixed_k = order, k
+    src0, dst0, _ = graph_network._graph_arrays(g, n)
+    _, _, src, dst = graph_network._locality_plan(g, n, k, src0)
+else:
+    dst = torch.arange(n, device=dev, dtype=torch.int32).repeat_interleave(k)
+    src = ((dst.long() + torch.randint(-4096, 4097, (n * k,), device=dev, generator=gen)) % n).to(torch.int32)
 P = m._pack(17, 4)
 p = P["rounds"][0]
 x = torch.randn(n, d, device=dev, generator=gen)
