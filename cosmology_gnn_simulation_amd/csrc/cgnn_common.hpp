@@ -105,6 +105,36 @@ struct Operand<CGNN_BF16, T> {
     }
 };
 
+// f32 emulated with three bf16 terms (CGNN_F32X3): x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1),
+// x3 = bf16(x - x1 - x2).
+struct bf16x8x3 {
+    bf16x8 p[3];
+};
+
+template <int T>
+struct Operand<CGNN_F32X3, T> {
+    bf16x8 v[3][2 * T];
+    template <bool RELU>
+    __device__ __forceinline__ void from_acc(const f32x16 (&acc)[T]) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float x = acc[t][8 * s + j];
+                    if (RELU) x = fmaxf(x, 0.f);
+                    const __bf16 x1 = (__bf16)x;
+                    const float r1 = x - (float)x1;
+                    const __bf16 x2 = (__bf16)r1;
+                    const float r2 = r1 - (float)x2;
+                    v[0][2 * t + s][j] = x1;
+                    v[1][2 * t + s][j] = x2;
+                    v[2][2 * t + s][j] = (__bf16)r2;
+                }
+    }
+};
+
 // out[o] += W[o-tile, :] . in   for every out tile; wp = packed weights.
 //
 // The packed layout is flat in MFMA issue order: fragment m = (o*KT + kt)*S + s lives at wp[m*64 + lane]
@@ -119,13 +149,37 @@ struct Frag<CGNN_F32> {
     typedef float type;
     static constexpr int S = 16;
     static constexpr int GS = 16;
+    static constexpr int NB = 2;
 };
 template <>
 struct Frag<CGNN_BF16> {
     typedef bf16x8 type;
     static constexpr int S = 2;
     static constexpr int GS = 4;
+    static constexpr int NB = 2;
 };
+
+template <>
+struct Frag<CGNN_F32X3> {
+    typedef bf16x8x3 type;
+    static constexpr int S = 2;
+    static constexpr int GS = 2;
+    static constexpr int NB = 3;    // weights stream from L2 at one wave per SIMD: keep two groups in flight
+};
+
+template <int KT>
+__device__ __forceinline__ f32x16 mfma_step(const bf16x8x3& a, const Operand<CGNN_F32X3, KT>& in, int kt, int s,
+                                            f32x16 c) {
+    const int i = 2 * kt + s;
+    // smallest terms first
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[2], in.v[0][i], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], in.v[2][i], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], in.v[1][i], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], in.v[0][i], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], in.v[1][i], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], in.v[0][i], c, 0, 0, 0);
+    return c;
+}
 
 template <int KT>
 __device__ __forceinline__ f32x16 mfma_step(float a, const Operand<CGNN_F32, KT>& in, int kt, int s, f32x16 c) {
@@ -162,6 +216,20 @@ struct BufW<CGNN_BF16> {
         return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, m * 1024, 0));
     }
 };
+template <>
+struct BufW<CGNN_F32X3> {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ BufW(const void* p, unsigned bytes)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000)) {}
+    __device__ __forceinline__ bf16x8x3 fetch(int m, int lane) const {
+        bf16x8x3 r;
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+            r.p[part] = __builtin_bit_cast(
+                bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, (m * 3 + part) * 1024, 0));
+        return r;
+    }
+};
 struct LdsW {
     LdsWeightPtr p;
     __device__ __forceinline__ explicit LdsW(LdsWeightPtr q) : p(q) {}
@@ -175,21 +243,26 @@ __device__ __forceinline__ void dense(f32x16 (&out)[OT], const Operand<PREC, KT>
     constexpr int M = OT * KT * S;
     constexpr int GS = (M < Frag<PREC>::GS) ? M : Frag<PREC>::GS;
     constexpr int NG = M / GS;
+    constexpr int NB = Frag<PREC>::NB;      // ring depth: NB - 1 groups of fragments in flight ahead of the MFMAs
     static_assert(M % GS == 0, "group size must divide the MFMA count");
-    A buf[2][GS];
+    A buf[NB][GS];
 #pragma unroll
-    for (int j = 0; j < GS; ++j) buf[0][j] = wp.fetch(j, lane);
+    for (int p = 0; p < NB - 1; ++p)
+        if (p < NG) {
+#pragma unroll
+            for (int j = 0; j < GS; ++j) buf[p][j] = wp.fetch(p * GS + j, lane);
+        }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        if (g + 1 < NG) {
+        if (g + NB - 1 < NG) {
 #pragma unroll
-            for (int j = 0; j < GS; ++j) buf[(g + 1) & 1][j] = wp.fetch((g + 1) * GS + j, lane);
+            for (int j = 0; j < GS; ++j) buf[(g + NB - 1) % NB][j] = wp.fetch((g + NB - 1) * GS + j, lane);
         }
 #pragma unroll
         for (int j = 0; j < GS; ++j) {
             const int m = g * GS + j;
             const int o = m / (KT * S), kt = (m / S) % KT, s = m % S;
-            out[o] = mfma_step<KT>(buf[g & 1][j], in, kt, s, out[o]);
+            out[o] = mfma_step<KT>(buf[g % NB][j], in, kt, s, out[o]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(CGNN_BLOCK) void project_kernel(const void* ws, con
                                                              typename PFmt<PFMT>::elem* __restrict__ pd) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int64_t tiles = (n + 31) / 32;
-    constexpr unsigned wbytes = DT * HT * 1024 * (PREC == CGNN_BF16 ? 2 : 4);
+    constexpr unsigned wbytes = DT * HT * 1024 * (PREC == CGNN_BF16 ? 2 : (PREC == CGNN_F32X3 ? 6 : 4));
     const BufW<PREC> wsrc_s(ws, wbytes), wsrc_d(wd, wbytes);
     const TileRange tr = tile_range(tiles);
     for (int64_t tile = tr.first; tile < tr.end; tile += tr.stride) {
@@ -153,6 +153,10 @@ int cgnn_mlp_rows(const cgnn_mlp* mlp, const float* x, int64_t n, int32_t ld_x, 
                   m.in_dim[0], ld_y, m.out_dim[m.nh]);
         return CGNN_ERR_INVALID_ARG;
     }
+    if (mlp->precision == CGNN_BF16_N16) {
+        set_error("cgnn_mlp_rows: CGNN_BF16_N16 weights are for cgnn_edge_block only");
+        return CGNN_ERR_UNSUPPORTED;
+    }
     if (n == 0) return CGNN_OK;
     const int hidden = m.out_dim[0];
     for (int l = 1; l < m.nh; ++l)
@@ -189,8 +193,10 @@ int cgnn_mlp_rows(const cgnn_mlp* mlp, const float* x, int64_t n, int32_t ld_x, 
 #define CGNN_PAIR(H, D)               \
     CGNN_TRY(CGNN_F32, 1, H, D)       \
     CGNN_TRY(CGNN_BF16, 1, H, D)      \
+    CGNN_TRY(CGNN_F32X3, 1, H, D)     \
     CGNN_TRY(CGNN_F32, D, H, 1)       \
-    CGNN_TRY(CGNN_BF16, D, H, 1)
+    CGNN_TRY(CGNN_BF16, D, H, 1)      \
+    CGNN_TRY(CGNN_F32X3, D, H, 1)
     CGNN_FOR_EACH_PAIR(CGNN_PAIR)
 #undef CGNN_PAIR
 #undef CGNN_TRY

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(CGNN_BLOCK) void node_block_kernel(MlpDev m, const 
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int64_t tiles = (n + 31) / 32;
     constexpr int D = 32 * DT, H = 32 * HT;
-    constexpr unsigned wbytes = DT * HT * 1024 * (PREC == CGNN_BF16 ? 2 : 4);
+    constexpr unsigned wbytes = DT * HT * 1024 * (PREC == CGNN_BF16 ? 2 : (PREC == CGNN_F32X3 ? 6 : 4));
     const BufW<PREC> wsrc_x(wx, wbytes), wsrc_a(wa, wbytes);
     const TileRange tr = tile_range(tiles);
     for (int64_t tile = tr.first; tile < tr.end; tile += tr.stride) {
@@ -93,6 +93,10 @@ extern "C" int cgnn_node_block(const cgnn_mlp* mlp, const cgnn_linear* w_x, cons
         set_error("cgnn_node_block: latent %d / hidden %d must be multiples of 32", latent, hidden);
         return CGNN_ERR_UNSUPPORTED;
     }
+    if (mlp->precision == CGNN_BF16_N16) {
+        set_error("cgnn_node_block: CGNN_BF16_N16 weights are for cgnn_edge_block only");
+        return CGNN_ERR_UNSUPPORTED;
+    }
     if (n == 0) return CGNN_OK;
     hipStream_t st = (hipStream_t)stream;
     const int HT = hidden / 32, DT = latent / 32, prec = mlp->precision;
@@ -103,6 +107,9 @@ extern "C" int cgnn_node_block(const cgnn_mlp* mlp, const cgnn_linear* w_x, cons
         if (prec == CGNN_F32)                                                                                       \
             node_block_kernel<CGNN_F32, Hh, Dd><<<grid, CGNN_BLOCK, 0, st>>>(m, w_x->w, w_agg->w, b1, x, agg, n,     \
                                                                             x_out, residual);                      \
+        else if (prec == CGNN_F32X3)                                                                                \
+            node_block_kernel<CGNN_F32X3, Hh, Dd><<<grid, CGNN_BLOCK, 0, st>>>(m, w_x->w, w_agg->w, b1, x, agg, n,   \
+                                                                              x_out, residual);                    \
         else                                                                                                        \
             node_block_kernel<CGNN_BF16, Hh, Dd><<<grid, CGNN_BLOCK, 0, st>>>(m, w_x->w, w_agg->w, b1, x, agg, n,    \
                                                                              x_out, residual);                     \

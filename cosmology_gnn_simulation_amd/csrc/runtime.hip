@@ -78,6 +78,31 @@ __global__ void pack_bf16_kernel(const float* __restrict__ w, int out_dim, int l
     wp[idx] = (__bf16)v;
 }
 
+// CGNN_F32X3: the bf16 fragment layout with three parts per fragment, [m][part][lane][j]; part p holds the p-th
+// bf16 term of the weight (w = w1 + w2 + w3).
+__global__ void pack_f32x3_kernel(const float* __restrict__ w, int out_dim, int ld, int col0, int ncols, int KT,
+                                  int64_t total, __bf16* __restrict__ wp) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int j = (int)(idx & 7);
+    const int l = (int)((idx >> 3) & 63);
+    const int64_t mp = idx >> 9;
+    const int part = (int)(mp % 3);
+    const int64_t m = mp / 3;
+    const int s = (int)(m & 1);
+    const int64_t okt = m >> 1;
+    const int kt = (int)(okt % KT);
+    const int o = (int)(okt / KT);
+    const int row = 32 * o + (l & 31);
+    const int k = 32 * kt + 16 * s + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+    const float v = (row < out_dim && k < ncols) ? w[(int64_t)row * ld + col0 + k] : 0.f;
+    const __bf16 w1 = (__bf16)v;
+    const float r1 = v - (float)w1;
+    const __bf16 w2 = (__bf16)r1;
+    const __bf16 w3 = (__bf16)(r1 - (float)w2);
+    wp[idx] = part == 0 ? w1 : (part == 1 ? w2 : w3);
+}
+
 // CGNN_BF16_N16: fragment m = O * KS + s (16-feature out tile O, 32-wide k-step s), A[row][k] of
 // v_mfma_f32_16x16x32_bf16: lane l holds row l & 15, k = 8 (l >> 4) + j  <->  feature phi(s, l >> 4, j) (n16.hpp)
 __global__ void pack_bf16_n16_kernel(const float* __restrict__ w, int out_dim, int ld, int col0, int ncols, int KS,
@@ -293,7 +318,7 @@ size_t cgnn_packed_linear_bytes(int32_t out_dim, int32_t ncols, int32_t precisio
     const size_t kt = (size_t)(ncols + 31) / 32;
     if (precision == CGNN_BF16_N16) return (size_t)((out_dim + 15) / 16) * kt * 1024;
     const size_t ot = (size_t)(out_dim + 31) / 32;
-    return ot * kt * 1024 * (precision == CGNN_BF16 ? 2 : 4);
+    return ot * kt * 1024 * (precision == CGNN_BF16 ? 2 : (precision == CGNN_F32X3 ? 6 : 4));
 }
 
 int cgnn_pack_linear(const float* w, int32_t out_dim, int32_t ld, int32_t col0, int32_t ncols, int32_t precision,
@@ -308,6 +333,12 @@ int cgnn_pack_linear(const float* w, int32_t out_dim, int32_t ld, int32_t col0, 
         const int64_t tot16 = (int64_t)((out_dim + 15) / 16) * KT * 512;
         pack_bf16_n16_kernel<<<(unsigned)((tot16 + CGNN_BLOCK - 1) / CGNN_BLOCK), CGNN_BLOCK, 0, st>>>(
             w, out_dim, ld, col0, ncols, KT, tot16, (__bf16*)packed);
+        return check_hip(hipGetLastError(), "cgnn_pack_linear launch");
+    }
+    if (precision == CGNN_F32X3) {
+        const int64_t tot3 = (int64_t)OT * KT * 1024 * 3;
+        pack_f32x3_kernel<<<(unsigned)((tot3 + CGNN_BLOCK - 1) / CGNN_BLOCK), CGNN_BLOCK, 0, st>>>(
+            w, out_dim, ld, col0, ncols, KT, tot3, (__bf16*)packed);
         return check_hip(hipGetLastError(), "cgnn_pack_linear launch");
     }
     const int64_t total = (int64_t)OT * KT * 1024;

@@ -36,7 +36,7 @@ def _graph(g):
                                                   (333, 17, 128, 128, 1, True), (257, 128, 128, 3, 2, False),
                                                   (64, 64, 64, 1, 3, False), (100, 17, 128, 64, 2, True),
                                                   (40, 9, 256, 256, 2, True)])
-@pytest.mark.parametrize("prec,tol", [("fp32", 2e-6), ("bf16", 3e-2)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-6), ("fp32x3", 2e-6), ("bf16", 3e-2)])
 def test_mlp_rows(n, fin, hid, out, nh, ln, prec, tol):
     gen = torch.Generator().manual_seed(n + fin)
     lin, sd, dims = [], {}, [fin] + [hid] * nh + [out]
@@ -235,6 +235,16 @@ def test_model_fp32_vs_reference_fixture(golden):
     with torch.no_grad():
         out = _model(g)(_graph(g))
     assert set(out) == {"acceleration", "temp_rate"}
+    assert rel_err(out["acceleration"].cpu(), torch.from_numpy(g["acceleration"])) <= TOL
+    assert rel_err(out["temp_rate"].cpu(), torch.from_numpy(g["temp_rate"])) <= TOL
+
+
+def test_model_fp32x3_node_path_meets_fp32_gate(golden):
+    """node_precision="fp32x3": f32 emulated by three bf16 terms on the bf16 matrix cores (6 MFMAs per product
+    block).  It must hold the same 1e-5 gate as the exact-f32 kernels, against the reference fixtures."""
+    g = golden
+    with torch.no_grad():
+        out = _model(g, node_precision="fp32x3", edge_precision="bf16")(_graph(g))
     assert rel_err(out["acceleration"].cpu(), torch.from_numpy(g["acceleration"])) <= TOL
     assert rel_err(out["temp_rate"].cpu(), torch.from_numpy(g["temp_rate"])) <= TOL
 
