@@ -268,6 +268,47 @@ __device__ __forceinline__ void dense(f32x16 (&out)[OT], const Operand<PREC, KT>
     }
 }
 
+// Same, restricted to fragments [M0, M1) of the layer, read from a source that holds just that range
+// (fragment m at local index m - M0): the LDS-cycled kernels stream a layer through LDS in chunks.
+template <int KT, int OT, int M0, int M1, int PREC, typename WSrc>
+__device__ __forceinline__ void dense_part(f32x16 (&out)[OT], const Operand<PREC, KT>& in, const WSrc& wp, int lane) {
+    typedef typename Frag<PREC>::type A;
+    constexpr int S = Frag<PREC>::S;
+    constexpr int M = M1 - M0;
+    constexpr int GS = (M < Frag<PREC>::GS) ? M : Frag<PREC>::GS;
+    constexpr int NG = M / GS;
+    static_assert(M % GS == 0 && M1 <= OT * KT * S, "bad fragment range");
+    A buf[2][GS];
+#pragma unroll
+    for (int j = 0; j < GS; ++j) buf[0][j] = wp.fetch(j, lane);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int j = 0; j < GS; ++j) buf[(g + 1) & 1][j] = wp.fetch((g + 1) * GS + j, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < GS; ++j) {
+            const int m = M0 + g * GS + j;
+            const int o = m / (KT * S), kt = (m / S) % KT, s = m % S;
+            out[o] = mfma_step<KT>(buf[g & 1][j], in, kt, s, out[o]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Three-part (CGNN_F32X3) fragments resident in LDS: [m][part][lane][8 bf16].
+struct LdsWx3 {
+    LdsWeightPtr p;
+    __device__ __forceinline__ explicit LdsWx3(LdsWeightPtr q) : p(q) {}
+    __device__ __forceinline__ bf16x8x3 fetch(int m, int lane) const {
+        bf16x8x3 r;
+#pragma unroll
+        for (int part = 0; part < 3; ++part) r.p[part] = p[(m * 3 + part) * 64 + lane];
+        return r;
+    }
+};
+
 // ---------------------------------------------------------------------------
 // act-layout tile helpers (T tiles of 32 features, one row per lane pair)
 // ---------------------------------------------------------------------------

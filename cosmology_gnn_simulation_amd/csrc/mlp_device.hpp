@@ -135,6 +135,34 @@ struct WSel<CGNN_BF16, true> {
     }
 };
 
+// Writers of the three cgnn_ptable formats from the 32-row act layout.
+template <int PFMT>
+struct PFmt;
+template <>
+struct PFmt<CGNN_P_F32> {
+    typedef float elem;
+    template <int HT>
+    static __device__ __forceinline__ void store(const f32x16 (&a)[HT], float* b, int64_t row, int h) {
+        PRow<CGNN_F32>::store<HT>(a, b, row, h);
+    }
+};
+template <>
+struct PFmt<CGNN_P_BF16_S32> {
+    typedef __bf16 elem;
+    template <int HT>
+    static __device__ __forceinline__ void store(const f32x16 (&a)[HT], __bf16* b, int64_t row, int h) {
+        PRow<CGNN_BF16>::store<HT>(a, b, row, h);
+    }
+};
+template <>
+struct PFmt<CGNN_P_BF16_S16> {
+    typedef __bf16 elem;
+    template <int HT>
+    static __device__ __forceinline__ void store(const f32x16 (&a)[HT], __bf16* b, int64_t row, int h) {
+        store_prow_s16<HT>(a, b, row, h);
+    }
+};
+
 // Hidden layers 1..nh-1 (Linear+ReLU, H->H) and the output layer (H->32*OT), starting from the ReLU'd
 // first-layer activations already in `oph`.  Leaves the pre-LayerNorm output in `out`.
 template <int PREC, bool WLDS, int HT, int OT>

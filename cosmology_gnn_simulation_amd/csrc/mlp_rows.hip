@@ -51,33 +51,6 @@ __global__ __launch_bounds__(CGNN_BLOCK) void mlp_rows_kernel(MlpDev m, const fl
     }
 }
 
-template <int PFMT>
-struct PFmt;
-template <>
-struct PFmt<CGNN_P_F32> {
-    typedef float elem;
-    template <int HT>
-    static __device__ __forceinline__ void store(const f32x16 (&a)[HT], float* b, int64_t row, int h) {
-        PRow<CGNN_F32>::store<HT>(a, b, row, h);
-    }
-};
-template <>
-struct PFmt<CGNN_P_BF16_S32> {
-    typedef __bf16 elem;
-    template <int HT>
-    static __device__ __forceinline__ void store(const f32x16 (&a)[HT], __bf16* b, int64_t row, int h) {
-        PRow<CGNN_BF16>::store<HT>(a, b, row, h);
-    }
-};
-template <>
-struct PFmt<CGNN_P_BF16_S16> {
-    typedef __bf16 elem;
-    template <int HT>
-    static __device__ __forceinline__ void store(const f32x16 (&a)[HT], __bf16* b, int64_t row, int h) {
-        store_prow_s16<HT>(a, b, row, h);
-    }
-};
-
 template <int PREC, int PFMT, int DT, int HT>
 __global__ __launch_bounds__(CGNN_BLOCK) void project_kernel(const void* ws, const void* wd, const float* __restrict__ bd,
                                                              int hidden, const float* __restrict__ x, int64_t n,

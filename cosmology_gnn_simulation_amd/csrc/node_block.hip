@@ -57,15 +57,184 @@ __global__ __launch_bounds__(CGNN_BLOCK) void node_block_kernel(MlpDev m, const 
     }
 }
 
+// --------------------------------------------------------------------------------------------------------
+// CGNN_F32X3, weights cycled through LDS.
+//
+// With three bf16 terms per weight a 128x128 layer is 96 KB and each wave would stream 3 KB of fragments per
+// 6 MFMAs from L2 -- exactly the L1 bandwidth of a CU, so the generic kernel ran the matrix cores at a third
+// of their rate.  Here the four waves of a workgroup share every fragment: a layer is cut into chunks of 16
+// fragments (48 KB), chunk i+1 is copied into one half of a two-slot LDS ring by LDS-DMA
+// (global_load_lds_dwordx4, no registers, one barrier per chunk) while the waves run the MFMAs of chunk i from
+// the other half.  Optionally the kernel also emits the next round's sender / receiver projections
+// (cgnn_project_nodes fused in: saves one launch and one read of x per round).
+#define CGNN_X3_CHUNK_FRAGS 16
+#define CGNN_X3_CHUNK_BYTES (CGNN_X3_CHUNK_FRAGS * 3 * 1024)
+#define CGNN_X3_MAX_CHUNKS 24
+
+struct X3Chunks {
+    const char* src[CGNN_X3_MAX_CHUNKS];   // packed bytes of each chunk, in consumption order
+    uint32_t bytes[CGNN_X3_MAX_CHUNKS];
+    int32_t count;
+};
+
+typedef __attribute__((address_space(3))) void* LdsVoidPtr;
+typedef const __attribute__((address_space(1))) void* GlobalVoidPtr;
+
+struct WeightRing {
+    const X3Chunks& c;
+    int wave, lane, next;   // next = index of the chunk to be consumed next (its DMA is already in flight)
+    __device__ __forceinline__ WeightRing(const X3Chunks& cc, int w, int l) : c(cc), wave(w), lane(l), next(0) {}
+    // every wave copies its quarter of chunk `idx` (1-KiB pieces wave, wave+4, ...) into ring slot idx & 1
+    __device__ __forceinline__ void issue(int idx) const {
+        const char* src = c.src[idx];
+        const uint32_t nb = c.bytes[idx];
+        char* dst = cgnn_smem + (idx & 1) * CGNN_X3_CHUNK_BYTES;
+        for (uint32_t off = wave * 1024u; off < nb; off += 4096u)
+            __builtin_amdgcn_global_load_lds((GlobalVoidPtr)(src + off + lane * 16), (LdsVoidPtr)(dst + off), 16, 0, 0);
+    }
+    // Make chunk `next` readable, start the copy of the one after it, return its LDS base.
+    __device__ __forceinline__ LdsWeightPtr acquire(bool more_tiles) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces have landed
+        __syncthreads();                                    // ... and everybody else's; slot (next+1)&1 is free
+        const int cur = next;
+        next = (next + 1 == c.count) ? 0 : next + 1;
+        if (next != 0 || more_tiles) issue(next);
+        return (LdsWeightPtr)(cgnn_smem + (cur & 1) * CGNN_X3_CHUNK_BYTES);
+    }
+};
+
+template <int T, int PFMT>
+__global__ __launch_bounds__(CGNN_BLOCK) void node_block_x3_kernel(MlpDev m, X3Chunks chunks,
+                                                                   const float* __restrict__ b1, const float* x,
+                                                                   const float* __restrict__ agg, int64_t n,
+                                                                   float* x_out, int residual,
+                                                                   const float* __restrict__ bd_next,
+                                                                   typename PFmt<PFMT>::elem* __restrict__ ps_next,
+                                                                   typename PFmt<PFMT>::elem* __restrict__ pd_next) {
+    constexpr int D = 32 * T;
+    constexpr int M = T * T * 2;                                   // fragments per layer
+    constexpr int CH = (M < CGNN_X3_CHUNK_FRAGS) ? M : CGNN_X3_CHUNK_FRAGS;
+    constexpr int NCH = M / CH;                                    // chunks per X3 layer
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t tiles = (n + 31) / 32;
+    // block-uniform tile loop (every wave must reach every barrier): wave w of the block takes tile bt + w
+    const int nb = gridDim.x, b = blockIdx.x;
+    int64_t bt, bend, bstride;
+    if ((nb & 7) == 0) {
+        const int xcd = b & 7, slot = b >> 3, per = nb >> 3;
+        bt = tiles * xcd / 8 + (int64_t)slot * CGNN_WAVES_PER_BLOCK;
+        bend = tiles * (xcd + 1) / 8;
+        bstride = (int64_t)per * CGNN_WAVES_PER_BLOCK;
+    } else {
+        bt = (int64_t)b * CGNN_WAVES_PER_BLOCK;
+        bend = tiles;
+        bstride = (int64_t)nb * CGNN_WAVES_PER_BLOCK;
+    }
+    WeightRing ring(chunks, wave, lane);
+    if (bt < bend) ring.issue(0);
+    for (; bt < bend; bt += bstride) {
+        const bool more = bt + bstride < bend;
+        const int64_t tile = bt + wave;
+        const bool valid = tile < bend;
+        const int64_t row = tile * 32 + r;
+        const int64_t rowc = (valid && row < n) ? row : n - 1;
+        f32x16 xv[T];
+        load_rows_full<T>(xv, x + rowc * D, h);
+        Operand<CGNN_F32X3, T> oph;
+        {
+            f32x16 acc[T];
+            acc_fill_bias<T>(acc, b1, D, h);
+            {
+                Operand<CGNN_F32X3, T> op;
+                op.template from_acc<false>(xv);
+#define CGNN_X3_LAYER(ACC, OP)                                                              \
+    {                                                                                        \
+        const LdsWx3 w0(ring.acquire(more));                                                 \
+        dense_part<T, T, 0, CH>(ACC, OP, w0, lane);                                          \
+        if (NCH == 2) {                                                                      \
+            const LdsWx3 w1(ring.acquire(more));                                             \
+            dense_part<T, T, (NCH == 2 ? CH : 0), (NCH == 2 ? 2 * CH : CH)>(ACC, OP, w1, lane); \
+        }                                                                                    \
+    }
+                CGNN_X3_LAYER(acc, op)
+            }
+            {
+                f32x16 av[T];
+                load_rows_full<T>(av, agg + rowc * D, h);
+                Operand<CGNN_F32X3, T> op;
+                op.template from_acc<false>(av);
+                CGNN_X3_LAYER(acc, op)
+            }
+            oph.template from_acc<true>(acc);
+        }
+        for (int l = 1; l < m.nh; ++l) {
+            f32x16 acc[T];
+            acc_fill_bias<T>(acc, m.b[l], D, h);
+            CGNN_X3_LAYER(acc, oph)
+            oph.template from_acc<true>(acc);
+        }
+        f32x16 out[T];
+        acc_fill_bias<T>(out, m.b[m.nh], D, h);
+        CGNN_X3_LAYER(out, oph)
+#undef CGNN_X3_LAYER
+        layer_norm_rows<T>(out, m.gamma, m.beta, h);
+        if (residual) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) out[t] += xv[t];
+        }
+        if (valid && row < n) store_rows_full<T>(out, x_out + row * D, h);
+        if (ps_next != nullptr) {   // block-uniform: the projection chunks are part of the ring sequence
+            Operand<CGNN_BF16, T> opb;
+            opb.template from_acc<false>(out);
+            {
+                f32x16 acc[T];
+                acc_fill_bias<T>(acc, (const float*)nullptr, D, h);
+                const LdsW ws(ring.acquire(more));
+                dense<T, T>(acc, opb, ws, lane);
+                if (valid && row < n) PFmt<PFMT>::template store<T>(acc, ps_next, row, h);
+            }
+            {
+                f32x16 acc[T];
+                acc_fill_bias<T>(acc, bd_next, D, h);
+                const LdsW wd(ring.acquire(more));
+                dense<T, T>(acc, opb, wd, lane);
+                if (valid && row < n) PFmt<PFMT>::template store<T>(acc, pd_next, row, h);
+            }
+        }
+    }
+}
+
 }  // namespace cgnn
 
 using namespace cgnn;
 
+template <int T, int PFMT>
+static int launch_node_x3(const MlpDev& m, const X3Chunks& ch, const float* b1, const float* x, const float* agg,
+                          int64_t n, float* x_out, int residual, const float* bd, void* ps, void* pd, hipStream_t st) {
+    auto kern = node_block_x3_kernel<T, PFMT>;
+    const int lds = 2 * CGNN_X3_CHUNK_BYTES;
+    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+                       "hipFuncSetAttribute(node_block_x3)");
+    if (rc != CGNN_OK) return rc;
+    const int grid = grid_for_tiles((n + 31) / 32, 1);
+    typedef typename PFmt<PFMT>::elem E;
+    kern<<<grid, CGNN_BLOCK, lds, st>>>(m, ch, b1, x, agg, n, x_out, residual, bd, (E*)ps, (E*)pd);
+    return check_hip(hipGetLastError(), "cgnn_node_block(x3) launch");
+}
+
 extern "C" int cgnn_node_block(const cgnn_mlp* mlp, const cgnn_linear* w_x, const cgnn_linear* w_agg, const float* x,
                                const float* agg, int64_t n, float* x_out, int32_t residual, int32_t latent,
-                               void* stream) {
+                               const cgnn_linear* ws_next, const cgnn_linear* wd_next, int32_t proj_precision,
+                               void* ps_next, void* pd_next, int32_t p_format, void* stream) {
     if (!mlp || !w_x || !w_agg || !w_x->w || !w_agg->w) {
         set_error("cgnn_node_block: invalid argument");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    const bool want_proj = ws_next != nullptr;
+    if (want_proj && (!wd_next || !ws_next->w || !wd_next->w || !ps_next || !pd_next)) {
+        set_error("cgnn_node_block: the projection epilogue needs ws_next, wd_next, ps_next and pd_next");
         return CGNN_ERR_INVALID_ARG;
     }
     // layer[0] of `mlp` is ignored: fill it with the x-half so that validation passes.
@@ -100,10 +269,52 @@ extern "C" int cgnn_node_block(const cgnn_mlp* mlp, const cgnn_linear* w_x, cons
     if (n == 0) return CGNN_OK;
     hipStream_t st = (hipStream_t)stream;
     const int HT = hidden / 32, DT = latent / 32, prec = mlp->precision;
-    const int grid = grid_for_tiles((n + 31) / 32);
     const float* b1 = w_x->b ? w_x->b : w_agg->b;
+
+    // ---- LDS-cycled F32X3 kernel (square layers up to 128), with the projection fused when it is bf16 ----
+    if (prec == CGNN_F32X3 && HT == DT && (DT == 1 || DT == 2 || DT == 4) && n >= 2048) {
+        const bool fuse = want_proj && proj_precision == CGNN_BF16 && ws_next->in_dim == latent &&
+                          ws_next->out_dim == latent && wd_next->in_dim == latent && wd_next->out_dim == latent &&
+                          (p_format == CGNN_P_BF16_S32 || p_format == CGNN_P_BF16_S16);
+        X3Chunks ch;
+        memset(&ch, 0, sizeof(ch));
+        const int M = DT * DT * 2;
+        const int CH = M < CGNN_X3_CHUNK_FRAGS ? M : CGNN_X3_CHUNK_FRAGS;
+        auto add_layer = [&](const void* w) {
+            for (int c = 0; c < M / CH; ++c) {
+                ch.src[ch.count] = reinterpret_cast<const char*>(w) + (size_t)c * CH * 3072;
+                ch.bytes[ch.count++] = (uint32_t)CH * 3072;
+            }
+        };
+        add_layer(w_x->w);
+        add_layer(w_agg->w);
+        for (int l = 1; l <= m.nh; ++l) add_layer(m.w[l]);
+        if (fuse) {
+            ch.src[ch.count] = reinterpret_cast<const char*>(ws_next->w);
+            ch.bytes[ch.count++] = (uint32_t)M * 1024;
+            ch.src[ch.count] = reinterpret_cast<const char*>(wd_next->w);
+            ch.bytes[ch.count++] = (uint32_t)M * 1024;
+        }
+        void* ps = fuse ? ps_next : nullptr;
+        void* pd = fuse ? pd_next : nullptr;
+        const float* bd = fuse ? wd_next->b : nullptr;
+        const int fmt = fuse ? p_format : CGNN_P_BF16_S32;
+#define CGNN_X3(Tt)                                                                                                 \
+    if (DT == Tt) {                                                                                                  \
+        rc = fmt == CGNN_P_BF16_S16                                                                                  \
+                 ? launch_node_x3<Tt, CGNN_P_BF16_S16>(m, ch, b1, x, agg, n, x_out, residual, bd, ps, pd, st)         \
+                 : launch_node_x3<Tt, CGNN_P_BF16_S32>(m, ch, b1, x, agg, n, x_out, residual, bd, ps, pd, st);        \
+    }
+        CGNN_X3(1) CGNN_X3(2) CGNN_X3(4)
+#undef CGNN_X3
+        if (rc != CGNN_OK || fuse || !want_proj) return rc;
+        return cgnn_project_nodes(ws_next, wd_next, proj_precision, x_out, n, ps_next, pd_next, p_format, stream);
+    }
+
+    const int grid = grid_for_tiles((n + 31) / 32);
+    bool launched = false;
 #define CGNN_PAIR(Hh, Dd)                                                                                          \
-    if (HT == Hh && DT == Dd) {                                                                                     \
+    if (!launched && HT == Hh && DT == Dd) {                                                                        \
         if (prec == CGNN_F32)                                                                                       \
             node_block_kernel<CGNN_F32, Hh, Dd><<<grid, CGNN_BLOCK, 0, st>>>(m, w_x->w, w_agg->w, b1, x, agg, n,     \
                                                                             x_out, residual);                      \
@@ -113,10 +324,15 @@ extern "C" int cgnn_node_block(const cgnn_mlp* mlp, const cgnn_linear* w_x, cons
         else                                                                                                        \
             node_block_kernel<CGNN_BF16, Hh, Dd><<<grid, CGNN_BLOCK, 0, st>>>(m, w_x->w, w_agg->w, b1, x, agg, n,    \
                                                                              x_out, residual);                     \
-        return check_hip(hipGetLastError(), "cgnn_node_block launch");                                              \
+        launched = true;                                                                                            \
     }
     CGNN_FOR_EACH_PAIR(CGNN_PAIR)
 #undef CGNN_PAIR
-    set_error("cgnn_node_block: no kernel for latent=%d hidden=%d", latent, hidden);
-    return CGNN_ERR_UNSUPPORTED;
+    if (!launched) {
+        set_error("cgnn_node_block: no kernel for latent=%d hidden=%d", latent, hidden);
+        return CGNN_ERR_UNSUPPORTED;
+    }
+    rc = check_hip(hipGetLastError(), "cgnn_node_block launch");
+    if (rc != CGNN_OK || !want_proj) return rc;
+    return cgnn_project_nodes(ws_next, wd_next, proj_precision, x_out, n, ps_next, pd_next, p_format, stream);
 }

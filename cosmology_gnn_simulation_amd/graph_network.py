@@ -239,13 +239,16 @@ class _PackedProcessor:
 
 
 def _run_round(p: _PackedProcessor, x: torch.Tensor, e: torch.Tensor, src, dst, fixed_k: int, message_source: str,
-               residual: bool, x_out=None, e_out=None, scratch=None):
-    """One message-passing round.  Returns (x_new, e_new)."""
+               residual: bool, x_out=None, e_out=None, scratch=None, projected: bool = False,
+               next_round: Optional[_PackedProcessor] = None):
+    """One message-passing round.  Returns (x_new, e_new).  ``projected``: the Ps/Pd tables in ``scratch`` were
+    already filled for this round (by the previous round's node kernel); ``next_round``: fill them for the next."""
     n = x.shape[0]
     ps = pd = agg = e_upd = None
     if scratch is not None:
         ps, pd, agg, e_upd = scratch
-    ps, pd = ops.project_nodes(p.ws, p.wd, x, ps, pd, p.p_format)
+    if not projected:
+        ps, pd = ops.project_nodes(p.ws, p.wd, x, ps, pd, p.p_format)
     if message_source == "edge" and e_upd is None:
         e_upd = e.empty_like()
     e_new = ops.edge_block(p.edge, ps, pd, src, dst, e, e_out, e_upd if message_source == "edge" else None, residual)
@@ -255,8 +258,11 @@ def _run_round(p: _PackedProcessor, x: torch.Tensor, e: torch.Tensor, src, dst, 
         agg = ops.aggregate(e_upd, None, dst, n, fixed_k, src.numel(), agg)
     else:
         raise ValueError(f"message_source must be 'x_j' or 'edge', got {message_source!r}")
-    x_new = ops.node_block(p.node, p.wx, p.wa, x, agg, x_out, residual)
-    return x_new, e_new
+    nxt = None
+    if next_round is not None and next_round.p_format == p.p_format and next_round.p_dtype == ps.dtype:
+        nxt = (next_round.ws, next_round.wd, ps, pd, next_round.p_format)
+    x_new = ops.node_block(p.node, p.wx, p.wa, x, agg, x_out, residual, nxt)
+    return x_new, e_new, nxt is not None
 
 
 class InteractionNetwork(nn.Module):
@@ -299,7 +305,7 @@ class InteractionNetwork(nn.Module):
             p = self._pack(x.shape[1])
             xf = x.float().contiguous()
             ef = ops.TiledRows.from_rows(edge_attr.float().contiguous())     # engine-internal edge layout
-            new_x, new_e = _run_round(p, xf, ef, src, dst, fixed_k, self.message_source, residual=False)
+            new_x, new_e, _ = _run_round(p, xf, ef, src, dst, fixed_k, self.message_source, residual=False)
         out = Data(x=new_x, edge_index=data.edge_index, edge_attr=new_e.to_rows())
         if hasattr(data, "globals"):
             out.globals = data.globals
@@ -412,10 +418,15 @@ class EncodeProcessDecode(nn.Module):
                 agg = torch.empty((n, xl.shape[1]), dtype=torch.float32, device=dev)
                 e_upd = el.empty_like() if self.message_source == "edge" else None
                 scratch = (ps, pd, agg, e_upd)
-            for p in P["rounds"]:
-                # residual streams updated in place (reference graph_network.py:181-182)
-                xl, el = _run_round(p, xl, el, src, dst, fixed_k, self.message_source, residual=True,
-                                    x_out=xl, e_out=el, scratch=scratch)
+            projected = False
+            rounds = P["rounds"]
+            for i, p in enumerate(rounds):
+                # residual streams updated in place (reference graph_network.py:181-182); the node kernel also
+                # emits the next round's sender / receiver projections
+                nxt = rounds[i + 1] if i + 1 < len(rounds) else None
+                xl, el, projected = _run_round(p, xl, el, src, dst, fixed_k, self.message_source, residual=True,
+                                               x_out=xl, e_out=el, scratch=scratch, projected=projected,
+                                               next_round=nxt)
             out = {"acceleration": ops.mlp_rows(P["dec_acc"], xl), "temp_rate": ops.mlp_rows(P["dec_tr"], xl)}
             if want_latents:
                 out["x_latent"], out["edge_latent"] = xl, el.to_rows()

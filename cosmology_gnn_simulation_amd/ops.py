@@ -284,16 +284,29 @@ def aggregate(table, gather: Optional[torch.Tensor], dst: Optional[torch.Tensor]
 
 
 def node_block(mlp: PackedMLP, w_x: PackedLinear, w_agg: PackedLinear, x: torch.Tensor, agg: torch.Tensor,
-               x_out: Optional[torch.Tensor] = None, residual: bool = True) -> torch.Tensor:
+               x_out: Optional[torch.Tensor] = None, residual: bool = True, next_projection=None) -> torch.Tensor:
+    """Fused node update.  ``next_projection = (ws, wd, ps, pd, p_format)`` additionally fills the next round's
+    Ps/Pd tables from ``x_out`` in the same call (fused into the kernel where a specialisation exists)."""
     x, agg = f32c(x, "x"), f32c(agg, "agg")
     n, latent = x.shape
     if x_out is None:
         x_out = torch.empty_like(x)
     sx, sa = w_x.struct(), w_agg.struct()
+    if next_projection is not None:
+        ws, wd, ps, pd, p_format = next_projection
+        s1, s2 = ws.struct(), wd.struct()
+        pdt = torch.float32 if p_format == _lib.P_F32 else torch.bfloat16
+        for t in (ps, pd):
+            require_device(t, "projection table")
+            if t.dtype != pdt or not t.is_contiguous() or t.shape != (n, ws.out_dim):
+                raise CgnnError("node_block: projection tables have the wrong dtype/shape")
+        proj = (C.byref(s1), C.byref(s2), ws.precision, ps.data_ptr(), pd.data_ptr(), p_format)
+    else:
+        proj = (None, None, 0, None, None, 0)
     with _timed("node_block", x.device):
         check(_lib.load().cgnn_node_block(C.byref(mlp.struct()), C.byref(sx), C.byref(sa), x.data_ptr(), agg.data_ptr(),
-                                      n, x_out.data_ptr(), 1 if residual else 0, latent, stream_ptr(x.device)),
-          "cgnn_node_block")
+                                          n, x_out.data_ptr(), 1 if residual else 0, latent, *proj,
+                                          stream_ptr(x.device)), "cgnn_node_block")
     return x_out
 
 

@@ -160,10 +160,15 @@ int cgnn_aggregate(const float* table, int32_t table_layout, const int32_t* gath
  *   x_out = x + u (residual != 0, graph_network.py:181) or u
  * w_x / w_agg are the column split of the node model's first Linear; the rest of
  * the MLP (hidden layers 1.., output layer, LayerNorm) is in `mlp` with
- * mlp->layer[0] ignored.  x_out may alias x. */
+ * mlp->layer[0] ignored.  x_out may alias x.
+ * Optional epilogue (ws_next != NULL): the next round's cgnn_project_nodes(ws_next,
+ * wd_next, proj_precision, x_out, n, ps_next, pd_next, p_format) in the same call --
+ * fused into the kernel where a fused specialisation exists, otherwise run after it. */
 int cgnn_node_block(const cgnn_mlp* mlp, const cgnn_linear* w_x, const cgnn_linear* w_agg,
                     const float* x, const float* agg, int64_t n, float* x_out,
-                    int32_t residual, int32_t latent, void* stream);
+                    int32_t residual, int32_t latent,
+                    const cgnn_linear* ws_next, const cgnn_linear* wd_next, int32_t proj_precision,
+                    void* ps_next, void* pd_next, int32_t p_format, void* stream);
 
 /* ---- K1+K2+K3: periodic k-NN graph + edge features -----------------------------
  * For each query particle q (all n, or query_ids[0..nq) when non-NULL) the k
