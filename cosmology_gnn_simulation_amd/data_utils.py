@@ -90,13 +90,30 @@ def _meta(metadata: dict, key: str, device) -> torch.Tensor:
     return torch.tensor(metadata[key], dtype=torch.float32, device=device)
 
 
+def _draw_reference_noise(pos_seq: torch.Tensor, tmp_seq: torch.Tensor, noise_std: float, temp_rate_std, dt: float,
+                          box_size: float):
+    """The reference's two RNG draws (data_utils.py:47,:63) on the CPU generator.  ``randn_like`` follows the
+    memory layout of its argument, so the draw order depends on the strides of the (permuted) windows; they are
+    reproduced on zero-filled host tensors with the inputs' shapes and strides (the noise does not depend on the
+    values), which spares device-resident windows a copy to the host."""
+    def host_like(t):
+        return t if not t.is_cuda else torch.empty_strided(t.shape, t.stride(), dtype=torch.float32).zero_()
+    pos_noise = generate_position_noise(host_like(pos_seq), noise_std, box_size, dt)
+    tmp_noise = generate_temperature_noise(host_like(tmp_seq), noise_std, temp_rate_std, dt)
+    return pos_noise, tmp_noise
+
+
 def preprocess(position_seq, temperature_seq, metadata, target_position=None, target_temperature=None,
-               noise_std=0.0, num_neighbors=16, dt=None, box_size=None, device: Optional[torch.device] = None):
+               noise_std=0.0, num_neighbors=16, dt=None, box_size=None, device: Optional[torch.device] = None,
+               reference_rng: bool = True):
     """Window ``[W, N, 3]`` / ``[W, N, 1]`` -> graph (reference data_utils.py:72-228).
 
     ``device`` (extension) selects the GPU; by default the inputs' device if they
     are already on one, else the current HIP device.  All returned tensors live
-    there, so the caller's ``graph.to(device)`` is a no-op."""
+    there, so the caller's ``graph.to(device)`` is a no-op.  ``reference_rng=False``
+    (extension, only honoured when ``noise_std == 0``) skips the two CPU random draws
+    the reference makes even for zero noise; results are identical, only the global
+    RNG stream is left untouched (used by the on-device rollout)."""
     dt = float(dt)
     box_size = float(box_size)
     if device is None:
@@ -111,11 +128,10 @@ def preprocess(position_seq, temperature_seq, metadata, target_position=None, ta
         target_position = target_position.float()
 
     # --- noise: drawn where the reference draws it (CPU RNG stream), then moved ---
-    cpu_pos = pos_seq.detach().cpu() if pos_seq.is_cuda else pos_seq
-    cpu_tmp = tmp_seq.detach().cpu() if tmp_seq.is_cuda else tmp_seq
-    pos_noise_cpu = generate_position_noise(cpu_pos, noise_std, box_size, dt)
-    trs_cpu = torch.tensor(metadata["temp_rate_std"], dtype=torch.float32)
-    tmp_noise_cpu = generate_temperature_noise(cpu_tmp, noise_std, trs_cpu, dt)
+    pos_noise_cpu = tmp_noise_cpu = None
+    if reference_rng or noise_std != 0.0:
+        trs_cpu = torch.tensor(metadata["temp_rate_std"], dtype=torch.float32)
+        pos_noise_cpu, tmp_noise_cpu = _draw_reference_noise(pos_seq, tmp_seq, noise_std, trs_cpu, dt, box_size)
 
     pos_seq = pos_seq.to(device)
     tmp_seq = tmp_seq.to(device)
@@ -159,7 +175,6 @@ def preprocess(position_seq, temperature_seq, metadata, target_position=None, ta
             tp = tp.permute(1, 0, 2).squeeze(1)
         elif tp.dim() == 2 and tp.shape[0] != n:
             tp = tp.reshape(-1, 3)
-        assert pos_noise_cpu.dim() == 3
         if noise_std != 0.0:
             tp += pos_noise_cpu[:, -1].to(tp.device)   # in place on the caller's tensor, like the reference (:182)
         tp = tp.to(device)

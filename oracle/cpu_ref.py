@@ -17,6 +17,7 @@ What it restates (all citations are into the read-only reference checkout):
 * ``data_utils.py:72-228``     preprocess           -> :func:`preprocess`
 * ``one_step_test.py:84-111``  one-step integrator  -> :func:`one_step`
 * ``train.py:107-118``         momentum term        -> :func:`momentum_conservation_loss`
+* ``render_rollout.py:26-90``  autoregressive rollout -> :func:`rollout` (restatement only, no reference fixture)
 
 Third-party arithmetic that is NOT in the reference checkout and is restated
 here from its published behaviour:
@@ -348,6 +349,27 @@ def momentum_conservation_loss(accelerations: Tensor, batch: Tensor, num_graphs:
         s = torch.sum(dv[batch == g], dim=0)
         total = total + torch.sum(s ** 2)
     return momentum_weight * total / num_graphs
+
+
+def rollout(sd: StateDict, nh: int, steps: int, coords: Tensor, energy: Tensor, metadata: dict, window_size: int,
+            num_neighbors: int, total_time: int) -> dict:
+    """render_rollout.py:26-90 restated (restatement only: that module imports h5py / matplotlib at import time
+    and cannot be loaded here, so this function has no reference-produced fixture)."""
+    dt, box = metadata["dt"], metadata["box_size"]
+    pos = [coords[i].float() for i in range(window_size)]
+    tmp = [energy[i].float() for i in range(window_size)]
+    with torch.no_grad():
+        for _ in range(total_time - window_size):
+            wp = torch.stack(pos[-window_size:])
+            wt = torch.stack(tmp[-window_size:])
+            g = preprocess(wp, wt, metadata, None, None, 0.0, num_neighbors, dt, box)
+            o = encode_process_decode(sd, g["x"], g["edge_index"], g["edge_attr"], nh, steps)
+            acc = o["acceleration"] * torch.tensor(metadata["acc_std"]) + torch.tensor(metadata["acc_mean"])
+            tr = o["temp_rate"] * torch.tensor(metadata["temp_rate_std"]) + torch.tensor(metadata["temp_rate_mean"])
+            v = (pos[-1] - pos[-2]) / dt + acc * dt
+            pos.append(torch.remainder(pos[-1] + v * dt, box))
+            tmp.append(tmp[-1] + tr * dt)
+    return {"Coordinates": torch.stack(pos), "InternalEnergy": torch.stack(tmp)}
 
 
 # --------------------------------------------------------------------------
