@@ -16,11 +16,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcgnn_hip.so")
 
 MAX_HIDDEN_LAYERS = 6
-F32, BF16, BF16_N16, F32X3 = 0, 1, 2, 3  # cgnn_precision
+F32, BF16, BF16_N16, F32X3, F32X3_N16 = 0, 1, 2, 3, 4  # cgnn_precision
 P_F32, P_BF16_S32, P_BF16_S16 = 0, 1, 2  # cgnn_ptable
 LDS_WEIGHT_BUDGET = 152 * 1024           # CGNN_LDS_WEIGHT_BUDGET in csrc/mlp_device.hpp
 PRECISIONS = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "bf16_n16": BF16_N16,
-              "fp32x3": F32X3, "f32x3": F32X3}
+              "fp32x3": F32X3, "f32x3": F32X3, "fp32x3_n16": F32X3_N16}
 
 # every symbol include/cgnn.h declares (tests check the library exports all of them)
 EXPORTS = (

@@ -293,7 +293,9 @@ __device__ __forceinline__ void dense_part(f32x16 (&out)[OT], const Operand<PREC
             const int o = m / (KT * S), kt = (m / S) % KT, s = m % S;
             out[o] = mfma_step<KT>(buf[g & 1][j], in, kt, s, out[o]);
         }
+#ifndef CGNN_NO_PART_BARRIER
         __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 }
 

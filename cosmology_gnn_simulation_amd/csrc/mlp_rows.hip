@@ -126,8 +126,8 @@ int cgnn_mlp_rows(const cgnn_mlp* mlp, const float* x, int64_t n, int32_t ld_x, 
                   m.in_dim[0], ld_y, m.out_dim[m.nh]);
         return CGNN_ERR_INVALID_ARG;
     }
-    if (mlp->precision == CGNN_BF16_N16) {
-        set_error("cgnn_mlp_rows: CGNN_BF16_N16 weights are for cgnn_edge_block only");
+    if (mlp->precision == CGNN_BF16_N16 || mlp->precision == CGNN_F32X3_N16) {
+        set_error("cgnn_mlp_rows: N16-packed weights are for cgnn_edge_block / cgnn_node_block only");
         return CGNN_ERR_UNSUPPORTED;
     }
     if (n == 0) return CGNN_OK;

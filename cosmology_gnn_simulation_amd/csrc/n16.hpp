@@ -119,3 +119,136 @@ __device__ __forceinline__ int n16_lane_offset(int c, int q, int half) {
 __device__ __forceinline__ constexpr int n16_tile_offset(int O) { return (4 * (O >> 1) + 2 * (O & 1)) * 64 * 4; }
 
 }  // namespace cgnn
+
+// ---------------------------------------------------------------------------------------------------------
+// CGNN_F32X3 arithmetic in the N16 layout (node kernel): three bf16 terms per value, six MFMAs per fragment.
+namespace cgnn {
+
+struct Operand16x3 {   // KS k-steps, three terms each
+    template <int KS>
+    struct T {
+        bf16x8 v[3][KS];
+    };
+};
+
+template <bool RELU, int KS>
+__device__ __forceinline__ void operand16x3(bf16x8 (&op)[3][KS], const f32x4 (&acc)[2 * KS]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = acc[2 * s + (j >> 2)][j & 3];
+            if (RELU) x = fmaxf(x, 0.f);
+            const __bf16 x1 = (__bf16)x;
+            const float r1 = x - (float)x1;
+            const __bf16 x2 = (__bf16)r1;
+            op[0][s][j] = x1;
+            op[1][s][j] = x2;
+            op[2][s][j] = (__bf16)(r1 - (float)x2);
+        }
+}
+
+// fragments [M0, M1) of a layer (m = O * KS + s), read from an LDS chunk holding exactly that range
+template <int KS, int OT, int M0, int M1>
+__device__ __forceinline__ void dense16x3_part(f32x4 (&out)[OT], const bf16x8 (&in)[3][KS], const LdsWx3& wp, int lane) {
+    constexpr int M = M1 - M0;
+    constexpr int GS = (M < 2) ? M : 2;
+    constexpr int NG = M / GS;
+    static_assert(M % GS == 0 && M1 <= OT * KS, "bad fragment range");
+    bf16x8x3 buf[2][GS];
+#pragma unroll
+    for (int j = 0; j < GS; ++j) buf[0][j] = wp.fetch(j, lane);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int j = 0; j < GS; ++j) buf[(g + 1) & 1][j] = wp.fetch((g + 1) * GS + j, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < GS; ++j) {
+            const int mm = M0 + g * GS + j;
+            const int o = mm / KS, s = mm % KS;
+            const bf16x8x3& a = buf[g & 1][j];
+            f32x4 c = out[o];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[2], in[0][s], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[0], in[2][s], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[1], in[1][s], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[1], in[0][s], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[0], in[1][s], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[0], in[0][s], c, 0, 0, 0);
+            out[o] = c;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// bias / LayerNorm vectors straight from global memory (the node kernel's LDS is taken by the weight ring)
+template <int OT>
+__device__ __forceinline__ void fill16_global(f32x4 (&acc)[OT], const float* __restrict__ b, int q) {
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+        if (b != nullptr)
+            acc[o] = *reinterpret_cast<const f32x4*>(b + 16 * o + 4 * q);
+        else
+            acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+template <int OT>
+__device__ __forceinline__ void layer_norm16_global(f32x4 (&a)[OT], const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, int q) {
+    float s = 0.f;
+#pragma unroll
+    for (int o = 0; o < OT; ++o)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += a[o][i];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    const float mean = s * (1.0f / (16 * OT));
+    float v = 0.f;
+#pragma unroll
+    for (int o = 0; o < OT; ++o)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float d = a[o][i] - mean;
+            v += d * d;
+        }
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    const float rstd = 1.0f / sqrtf(v * (1.0f / (16 * OT)) + 1e-5f);
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + 16 * o + 4 * q);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + 16 * o + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[o][i] = (a[o][i] - mean) * rstd * gm[i] + bt[i];
+    }
+}
+
+// P rows written from the N16 layout.  S16: lane (c, q) owns the contiguous run [q][O][i].  S32: feature
+// 16 O + 4 q + i = 32 t + 8 g + 4 h + i with t = O >> 1, g = 2 (O & 1) + (q >> 1), h = q & 1.
+template <int PFMT, int OT>
+__device__ __forceinline__ void store_p16(const f32x4 (&acc)[OT], __bf16* __restrict__ base, int64_t row, int q) {
+    __bf16* rp = base + row * (16 * OT);
+    if (PFMT == CGNN_P_BF16_S16) {
+        bf16x8* p = reinterpret_cast<bf16x8*>(rp + q * (4 * OT));
+#pragma unroll
+        for (int j = 0; j < OT / 2; ++j) {
+            bf16x8 v;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = (__bf16)acc[2 * j + (c >> 2)][c & 3];
+            p[j] = v;
+        }
+    } else {
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+            const int t = o >> 1, g = 2 * (o & 1) + (q >> 1), hh = q & 1;
+            bf16x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = (__bf16)acc[o][c];
+            *reinterpret_cast<bf16x4*>(rp + hh * (8 * OT) + (4 * t + g) * 4) = v;
+        }
+    }
+}
+
+}  // namespace cgnn

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "mlp_device.hpp"
+#include "weight_ring.hpp"
 
 namespace cgnn {
 
@@ -67,42 +68,6 @@ __global__ __launch_bounds__(CGNN_BLOCK) void node_block_kernel(MlpDev m, const 
 // (global_load_lds_dwordx4, no registers, one barrier per chunk) while the waves run the MFMAs of chunk i from
 // the other half.  Optionally the kernel also emits the next round's sender / receiver projections
 // (cgnn_project_nodes fused in: saves one launch and one read of x per round).
-#define CGNN_X3_CHUNK_FRAGS 16
-#define CGNN_X3_CHUNK_BYTES (CGNN_X3_CHUNK_FRAGS * 3 * 1024)
-#define CGNN_X3_MAX_CHUNKS 24
-
-struct X3Chunks {
-    const char* src[CGNN_X3_MAX_CHUNKS];   // packed bytes of each chunk, in consumption order
-    uint32_t bytes[CGNN_X3_MAX_CHUNKS];
-    int32_t count;
-};
-
-typedef __attribute__((address_space(3))) void* LdsVoidPtr;
-typedef const __attribute__((address_space(1))) void* GlobalVoidPtr;
-
-struct WeightRing {
-    const X3Chunks& c;
-    int wave, lane, next;   // next = index of the chunk to be consumed next (its DMA is already in flight)
-    __device__ __forceinline__ WeightRing(const X3Chunks& cc, int w, int l) : c(cc), wave(w), lane(l), next(0) {}
-    // every wave copies its quarter of chunk `idx` (1-KiB pieces wave, wave+4, ...) into ring slot idx & 1
-    __device__ __forceinline__ void issue(int idx) const {
-        const char* src = c.src[idx];
-        const uint32_t nb = c.bytes[idx];
-        char* dst = cgnn_smem + (idx & 1) * CGNN_X3_CHUNK_BYTES;
-        for (uint32_t off = wave * 1024u; off < nb; off += 4096u)
-            __builtin_amdgcn_global_load_lds((GlobalVoidPtr)(src + off + lane * 16), (LdsVoidPtr)(dst + off), 16, 0, 0);
-    }
-    // Make chunk `next` readable, start the copy of the one after it, return its LDS base.
-    __device__ __forceinline__ LdsWeightPtr acquire(bool more_tiles) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces have landed
-        __syncthreads();                                    // ... and everybody else's; slot (next+1)&1 is free
-        const int cur = next;
-        next = (next + 1 == c.count) ? 0 : next + 1;
-        if (next != 0 || more_tiles) issue(next);
-        return (LdsWeightPtr)(cgnn_smem + (cur & 1) * CGNN_X3_CHUNK_BYTES);
-    }
-};
-
 template <int T, int PFMT>
 __global__ __launch_bounds__(CGNN_BLOCK) void node_block_x3_kernel(MlpDev m, X3Chunks chunks,
                                                                    const float* __restrict__ b1, const float* x,
@@ -209,6 +174,13 @@ __global__ __launch_bounds__(CGNN_BLOCK) void node_block_x3_kernel(MlpDev m, X3C
 
 using namespace cgnn;
 
+namespace cgnn {
+int node_block_x3n16(const MlpDev& m, const cgnn_linear* w_x, const cgnn_linear* w_agg, const float* x,
+                     const float* agg, int64_t n, float* x_out, int residual, int T, bool fuse,
+                     const cgnn_linear* ws_next, const cgnn_linear* wd_next, void* ps_next, void* pd_next, int p_format,
+                     hipStream_t st);   // node_block_n16.hip
+}
+
 template <int T, int PFMT>
 static int launch_node_x3(const MlpDev& m, const X3Chunks& ch, const float* b1, const float* x, const float* agg,
                           int64_t n, float* x_out, int residual, const float* bd, void* ps, void* pd, hipStream_t st) {
@@ -270,6 +242,29 @@ extern "C" int cgnn_node_block(const cgnn_mlp* mlp, const cgnn_linear* w_x, cons
     hipStream_t st = (hipStream_t)stream;
     const int HT = hidden / 32, DT = latent / 32, prec = mlp->precision;
     const float* b1 = w_x->b ? w_x->b : w_agg->b;
+
+    // ---- 16-row F32X3 kernel (weights packed CGNN_F32X3_N16): two waves per SIMD ----
+    if (prec == CGNN_F32X3_N16) {
+        if (HT != DT || !(DT == 1 || DT == 2 || DT == 4)) {
+            set_error("cgnn_node_block: CGNN_F32X3_N16 needs hidden == latent in {32, 64, 128}");
+            return CGNN_ERR_UNSUPPORTED;
+        }
+        bool fuse = false;
+        if (want_proj) {
+            const bool shapes = ws_next->in_dim == latent && ws_next->out_dim == latent && wd_next->in_dim == latent &&
+                                wd_next->out_dim == latent;
+            fuse = shapes && proj_precision == CGNN_BF16_N16 &&
+                   (p_format == CGNN_P_BF16_S32 || p_format == CGNN_P_BF16_S16);
+            if (!fuse && proj_precision == CGNN_BF16_N16) {
+                set_error("cgnn_node_block: CGNN_BF16_N16 projection weights can only be used fused (square, bf16 table)");
+                return CGNN_ERR_UNSUPPORTED;
+            }
+        }
+        rc = node_block_x3n16(m, w_x, w_agg, x, agg, n, x_out, residual, DT, fuse, ws_next, wd_next, ps_next, pd_next,
+                              p_format, st);
+        if (rc != CGNN_OK || fuse || !want_proj) return rc;
+        return cgnn_project_nodes(ws_next, wd_next, proj_precision, x_out, n, ps_next, pd_next, p_format, stream);
+    }
 
     // ---- LDS-cycled F32X3 kernel (square layers up to 128), with the projection fused when it is bf16 ----
     if (prec == CGNN_F32X3 && HT == DT && (DT == 1 || DT == 2 || DT == 4) && n >= 2048) {

@@ -1,0 +1,175 @@
+// cgnn_node_block, CGNN_F32X3_N16 variant: 16 nodes per wave (v_mfma_f32_16x16x32_bf16, see n16.hpp), 512-thread
+// workgroups = two waves per SIMD, three-term weights streamed through the LDS ring (weight_ring.hpp).
+//
+// The 32-row F32X3 kernel needs ~380 registers per wave, i.e. one wave per SIMD, and its VALU work (splitting every
+// activation into three bf16 terms: ~2900 instructions per tile against 832 MFMAs) cannot overlap its own MFMAs.
+// Halving the rows per wave fits two waves per SIMD, so one wave's splitting and LayerNorm run under the other
+// wave's MFMAs.
+#include <string.h>
+
+#include "n16.hpp"
+#include "weight_ring.hpp"
+
+namespace cgnn {
+
+#define CGNN_NODE_N16_BLOCK 512
+
+template <int T, int PFMT>
+__global__ __launch_bounds__(CGNN_NODE_N16_BLOCK) void node_block_x3n16_kernel(
+    MlpDev m, X3Chunks chunks, const float* __restrict__ b1, const float* x, const float* __restrict__ agg, int64_t n,
+    float* x_out, int residual, const float* __restrict__ bd_next, __bf16* __restrict__ ps_next,
+    __bf16* __restrict__ pd_next) {
+    constexpr int D = 32 * T, OT = 2 * T, KS = T;
+    constexpr int M = OT * KS;                                     // fragments per layer
+    constexpr int CH = (M < CGNN_X3_CHUNK_FRAGS) ? M : CGNN_X3_CHUNK_FRAGS;
+    constexpr int NCH = M / CH;
+    constexpr int WAVES = CGNN_NODE_N16_BLOCK / 64;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t tiles = (n + 15) / 16;
+    const int nb = gridDim.x, b = blockIdx.x;
+    int64_t bt, bend, bstride;                                     // block-uniform loop: every wave meets every barrier
+    if ((nb & 7) == 0) {
+        const int xcd = b & 7, slot = b >> 3, per = nb >> 3;
+        bt = tiles * xcd / 8 + (int64_t)slot * WAVES;
+        bend = tiles * (xcd + 1) / 8;
+        bstride = (int64_t)per * WAVES;
+    } else {
+        bt = (int64_t)b * WAVES;
+        bend = tiles;
+        bstride = (int64_t)nb * WAVES;
+    }
+    WeightRing ring(chunks, wave, lane);
+    if (bt < bend) ring.issue(0);
+    for (; bt < bend; bt += bstride) {
+        const bool more = bt + bstride < bend;
+        const int64_t tile = bt + wave;
+        const bool valid = tile < bend;
+        const int64_t row = tile * 16 + c;
+        const bool live = valid && row < n;
+        const int64_t rowc = live ? row : n - 1;
+        const int foff = 4 * q;                                    // lane's feature offset inside a 16-feature tile
+
+#define CGNN_N16_LAYER(ACC, OP)                                                                       \
+    {                                                                                                 \
+        const LdsWx3 w0(ring.acquire(more));                                                          \
+        dense16x3_part<KS, OT, 0, CH>(ACC, OP, w0, lane);                                             \
+        if (NCH == 2) {                                                                               \
+            const LdsWx3 w1(ring.acquire(more));                                                      \
+            dense16x3_part<KS, OT, (NCH == 2 ? CH : 0), (NCH == 2 ? 2 * CH : CH)>(ACC, OP, w1, lane); \
+        }                                                                                             \
+    }
+
+        f32x4 xv[OT];
+#pragma unroll
+        for (int o = 0; o < OT; ++o) xv[o] = *reinterpret_cast<const f32x4*>(x + rowc * D + 16 * o + foff);
+        bf16x8 oph[3][KS];
+        {
+            f32x4 acc[OT];
+            fill16_global<OT>(acc, b1, q);
+            {
+                bf16x8 op[3][KS];
+                operand16x3<false, KS>(op, xv);
+                CGNN_N16_LAYER(acc, op)
+            }
+            {
+                f32x4 av[OT];
+#pragma unroll
+                for (int o = 0; o < OT; ++o) av[o] = *reinterpret_cast<const f32x4*>(agg + rowc * D + 16 * o + foff);
+                bf16x8 op[3][KS];
+                operand16x3<false, KS>(op, av);
+                CGNN_N16_LAYER(acc, op)
+            }
+            operand16x3<true, KS>(oph, acc);
+        }
+        for (int l = 1; l < m.nh; ++l) {
+            f32x4 acc[OT];
+            fill16_global<OT>(acc, m.b[l], q);
+            CGNN_N16_LAYER(acc, oph)
+            operand16x3<true, KS>(oph, acc);
+        }
+        f32x4 out[OT];
+        fill16_global<OT>(out, m.b[m.nh], q);
+        CGNN_N16_LAYER(out, oph)
+#undef CGNN_N16_LAYER
+        layer_norm16_global<OT>(out, m.gamma, m.beta, q);
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+            if (residual) out[o] += xv[o];
+            if (live) *reinterpret_cast<f32x4*>(x_out + row * D + 16 * o + foff) = out[o];
+        }
+        if (ps_next != nullptr) {   // block-uniform: the projection chunks are part of the ring sequence
+            bf16x8 opb[KS];
+            operand16<false, KS>(opb, out);
+            {
+                f32x4 acc[OT];
+                fill16_global<OT>(acc, nullptr, q);
+                const LdsW ws(ring.acquire(more));
+                dense16<KS, OT>(acc, opb, ws, lane);
+                if (live) store_p16<PFMT, OT>(acc, ps_next, row, q);
+            }
+            {
+                f32x4 acc[OT];
+                fill16_global<OT>(acc, bd_next, q);
+                const LdsW wd(ring.acquire(more));
+                dense16<KS, OT>(acc, opb, wd, lane);
+                if (live) store_p16<PFMT, OT>(acc, pd_next, row, q);
+            }
+        }
+    }
+}
+
+template <int T, int PFMT>
+static int launch(const MlpDev& m, const X3Chunks& ch, const float* b1, const float* x, const float* agg, int64_t n,
+                  float* x_out, int residual, const float* bd, void* ps, void* pd, hipStream_t st) {
+    auto kern = node_block_x3n16_kernel<T, PFMT>;
+    const int lds = 2 * CGNN_X3_CHUNK_BYTES;
+    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+                       "hipFuncSetAttribute(node_block_x3n16)");
+    if (rc != CGNN_OK) return rc;
+    const int grid = grid_for_tiles((n + 15) / 16, 1, CGNN_NODE_N16_BLOCK / 64);
+    kern<<<grid, CGNN_NODE_N16_BLOCK, lds, st>>>(m, ch, b1, x, agg, n, x_out, residual, bd, (__bf16*)ps, (__bf16*)pd);
+    return check_hip(hipGetLastError(), "cgnn_node_block(x3 n16) launch");
+}
+
+// Called by cgnn_node_block (node_block.hip) after argument validation.  `fuse`: emit the projections in-kernel.
+int node_block_x3n16(const MlpDev& m, const cgnn_linear* w_x, const cgnn_linear* w_agg, const float* x,
+                     const float* agg, int64_t n, float* x_out, int residual, int T, bool fuse,
+                     const cgnn_linear* ws_next, const cgnn_linear* wd_next, void* ps_next, void* pd_next, int p_format,
+                     hipStream_t st) {
+    X3Chunks ch;
+    memset(&ch, 0, sizeof(ch));
+    const int M = 2 * T * T;
+    const int CH = M < CGNN_X3_CHUNK_FRAGS ? M : CGNN_X3_CHUNK_FRAGS;
+    auto add_layer = [&](const void* w) {
+        for (int c = 0; c < M / CH; ++c) {
+            ch.src[ch.count] = reinterpret_cast<const char*>(w) + (size_t)c * CH * 3072;
+            ch.bytes[ch.count++] = (uint32_t)CH * 3072;
+        }
+    };
+    add_layer(w_x->w);
+    add_layer(w_agg->w);
+    for (int l = 1; l <= m.nh; ++l) add_layer(m.w[l]);
+    if (fuse) {
+        ch.src[ch.count] = reinterpret_cast<const char*>(ws_next->w);
+        ch.bytes[ch.count++] = (uint32_t)M * 1024;
+        ch.src[ch.count] = reinterpret_cast<const char*>(wd_next->w);
+        ch.bytes[ch.count++] = (uint32_t)M * 1024;
+    }
+    const float* b1 = w_x->b ? w_x->b : w_agg->b;
+    const float* bd = fuse ? wd_next->b : nullptr;
+    void* ps = fuse ? ps_next : nullptr;
+    void* pd = fuse ? pd_next : nullptr;
+    const bool s16 = fuse && p_format == CGNN_P_BF16_S16;
+#define CGNN_GO(Tt)                                                                                           \
+    if (T == Tt)                                                                                               \
+        return s16 ? launch<Tt, CGNN_P_BF16_S16>(m, ch, b1, x, agg, n, x_out, residual, bd, ps, pd, st)         \
+                   : launch<Tt, CGNN_P_BF16_S32>(m, ch, b1, x, agg, n, x_out, residual, bd, ps, pd, st);
+    CGNN_GO(1) CGNN_GO(2) CGNN_GO(4)
+#undef CGNN_GO
+    set_error("cgnn_node_block: no CGNN_F32X3_N16 kernel for latent=%d", 32 * T);
+    return CGNN_ERR_UNSUPPORTED;
+}
+
+}  // namespace cgnn

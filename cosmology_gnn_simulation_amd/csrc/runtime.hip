@@ -120,6 +120,28 @@ __global__ void pack_bf16_n16_kernel(const float* __restrict__ w, int out_dim, i
     wp[idx] = (__bf16)v;
 }
 
+// CGNN_F32X3_N16: the N16 fragment order with three bf16 terms per weight, [m][part][lane][j].
+__global__ void pack_f32x3_n16_kernel(const float* __restrict__ w, int out_dim, int ld, int col0, int ncols, int KS,
+                                      int64_t total, __bf16* __restrict__ wp) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int j = (int)(idx & 7);
+    const int l = (int)((idx >> 3) & 63);
+    const int64_t mp = idx >> 9;
+    const int part = (int)(mp % 3);
+    const int64_t m = mp / 3;
+    const int s = (int)(m % KS);
+    const int o = (int)(m / KS);
+    const int row = 16 * o + (l & 15);
+    const int k = 32 * s + 16 * (j >> 2) + 4 * (l >> 4) + (j & 3);
+    const float v = (row < out_dim && k < ncols) ? w[(int64_t)row * ld + col0 + k] : 0.f;
+    const __bf16 w1 = (__bf16)v;
+    const float r1 = v - (float)w1;
+    const __bf16 w2 = (__bf16)r1;
+    const __bf16 w3 = (__bf16)(r1 - (float)w2);
+    wp[idx] = part == 0 ? w1 : (part == 1 ? w2 : w3);
+}
+
 // ------------------------------------------------------------------ aggregation
 // Fixed in-degree, receiver-sorted: one (row, 16-byte chunk) per thread; the k
 // neighbour rows are read with 16 B per lane, a row's chunks on adjacent lanes.
@@ -317,6 +339,7 @@ size_t cgnn_packed_linear_bytes(int32_t out_dim, int32_t ncols, int32_t precisio
     if (out_dim <= 0 || ncols <= 0) return 0;
     const size_t kt = (size_t)(ncols + 31) / 32;
     if (precision == CGNN_BF16_N16) return (size_t)((out_dim + 15) / 16) * kt * 1024;
+    if (precision == CGNN_F32X3_N16) return (size_t)((out_dim + 15) / 16) * kt * 3072;
     const size_t ot = (size_t)(out_dim + 31) / 32;
     return ot * kt * 1024 * (precision == CGNN_BF16 ? 2 : (precision == CGNN_F32X3 ? 6 : 4));
 }
@@ -329,6 +352,12 @@ int cgnn_pack_linear(const float* w, int32_t out_dim, int32_t ld, int32_t col0, 
     }
     const int OT = (out_dim + 31) / 32, KT = (ncols + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
+    if (precision == CGNN_F32X3_N16) {
+        const int64_t tot = (int64_t)((out_dim + 15) / 16) * KT * 512 * 3;
+        pack_f32x3_n16_kernel<<<(unsigned)((tot + CGNN_BLOCK - 1) / CGNN_BLOCK), CGNN_BLOCK, 0, st>>>(
+            w, out_dim, ld, col0, ncols, KT, tot, (__bf16*)packed);
+        return check_hip(hipGetLastError(), "cgnn_pack_linear launch");
+    }
     if (precision == CGNN_BF16_N16) {
         const int64_t tot16 = (int64_t)((out_dim + 15) / 16) * KT * 512;
         pack_bf16_n16_kernel<<<(unsigned)((tot16 + CGNN_BLOCK - 1) / CGNN_BLOCK), CGNN_BLOCK, 0, st>>>(

@@ -233,9 +233,18 @@ class _PackedProcessor:
         self.p_format = ops.p_table_format(self.edge.precision)
         self.p_dtype = ops.p_table_dtype(self.edge.precision)
         # cat([x, aggregated]) -> [Wx | Wa]                         (reference graph_network.py:94)
-        self.wx = ops.PackedLinear(w1n, b1n, node_precision, 0, D)
-        self.wa = ops.PackedLinear(w1n, None, node_precision, D, D)
-        self.node = _pack_mlp(net.node_model, node_precision, first_layer_cols=(0, D))
+        node_fmt = node_precision
+        if ops._prec(node_precision) == _lib.F32X3 and D <= 128 and w1n.shape[0] == D:
+            node_fmt = "fp32x3_n16"     # square layers <= 128: the 16-row, two-waves-per-SIMD node kernel
+        self.wx = ops.PackedLinear(w1n, b1n, node_fmt, 0, D)
+        self.wa = ops.PackedLinear(w1n, None, node_fmt, D, D)
+        self.node = _pack_mlp(net.node_model, node_fmt, first_layer_cols=(0, D))
+        # projection weights in the packing the PREVIOUS round's node kernel can fuse (it produces this round's
+        # Ps / Pd): the N16 node kernel takes CGNN_BF16_N16, everything else the 32-row packing above
+        self.ws_fused, self.wd_fused = self.ws, self.wd
+        if self.node.precision == _lib.F32X3_N16 and self.ws.precision == _lib.BF16 and w1e.shape[0] == D:
+            self.ws_fused = ops.PackedLinear(w1e, None, "bf16_n16", 0, D)
+            self.wd_fused = ops.PackedLinear(w1e, b1e, "bf16_n16", D, D)
 
 
 def _run_round(p: _PackedProcessor, x: torch.Tensor, e: torch.Tensor, src, dst, fixed_k: int, message_source: str,
@@ -260,7 +269,9 @@ def _run_round(p: _PackedProcessor, x: torch.Tensor, e: torch.Tensor, src, dst, 
         raise ValueError(f"message_source must be 'x_j' or 'edge', got {message_source!r}")
     nxt = None
     if next_round is not None and next_round.p_format == p.p_format and next_round.p_dtype == ps.dtype:
-        nxt = (next_round.ws, next_round.wd, ps, pd, next_round.p_format)
+        fused_ok = p.node.precision == _lib.F32X3_N16 and next_round.ws_fused.precision == _lib.BF16_N16
+        nxt = (next_round.ws_fused if fused_ok else next_round.ws, next_round.wd_fused if fused_ok else next_round.wd,
+               ps, pd, next_round.p_format)
     x_new = ops.node_block(p.node, p.wx, p.wa, x, agg, x_out, residual, nxt)
     return x_new, e_new, nxt is not None
 

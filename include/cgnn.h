@@ -45,11 +45,14 @@ typedef enum {
     CGNN_BF16 = 1,     /* bf16 operands, v_mfma_f32_32x32x16_bf16, f32 accumulate           */
     CGNN_BF16_N16 = 2, /* same arithmetic as CGNN_BF16, weights packed for the 16-edge-per-
                           wave kernel (v_mfma_f32_16x16x32_bf16); cgnn_edge_block only      */
-    CGNN_F32X3 = 3     /* f32 emulated on the bf16 matrix cores: operands split into three bf16
+    CGNN_F32X3 = 3,    /* f32 emulated on the bf16 matrix cores: operands split into three bf16
                           terms (8+8+8 significand bits), the six products whose weight is
                           >= 2^-16 accumulated in f32 (a1b1,a1b2,a2b1,a2b2,a1b3,a3b1); dropped
                           terms are <= 2^-24 relative.  2.7x the f32-MFMA rate at f32-level
                           error; cgnn_mlp_rows and cgnn_node_block                          */
+    CGNN_F32X3_N16 = 4 /* CGNN_F32X3 arithmetic, weights packed for the 16-row-per-wave node kernel
+                          (v_mfma_f32_16x16x32_bf16, two waves per SIMD); cgnn_node_block only,
+                          square layers, its projection epilogue takes CGNN_BF16_N16 weights    */
 } cgnn_precision;
 
 /* Element type / row order of the Ps, Pd gather tables (cgnn_project_nodes -> cgnn_edge_block).
