@@ -45,6 +45,32 @@ __device__ __forceinline__ void dense16(f32x4 (&out)[OT], const bf16x8 (&in)[KS]
     }
 }
 
+// fragments [M0, M1) only, read from a source holding exactly that range
+template <int KS, int OT, int M0, int M1>
+__device__ __forceinline__ void dense16_part(f32x4 (&out)[OT], const bf16x8 (&in)[KS], const LdsW& wp, int lane) {
+    constexpr int M = M1 - M0;
+    constexpr int GS = (M < 4) ? M : 4;
+    constexpr int NG = M / GS;
+    static_assert(M % GS == 0 && M1 <= OT * KS, "bad fragment range");
+    bf16x8 buf[2][GS];
+#pragma unroll
+    for (int j = 0; j < GS; ++j) buf[0][j] = wp.fetch(j, lane);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int j = 0; j < GS; ++j) buf[(g + 1) & 1][j] = wp.fetch((g + 1) * GS + j, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < GS; ++j) {
+            const int mm = M0 + g * GS + j;
+            const int o = mm / KS, s = mm % KS;
+            out[o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(buf[g & 1][j], in[s], out[o], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <bool RELU, int KS>
 __device__ __forceinline__ void operand16(bf16x8 (&op)[KS], const f32x4 (&acc)[2 * KS]) {
 #pragma unroll

@@ -12,7 +12,9 @@
 
 namespace cgnn {
 
-#define CGNN_NODE_N16_BLOCK 512
+#define CGNN_NODE_N16_BLOCK 512          // (two 256-thread workgroups per CU with 24-KB chunks measured the same)
+#define CGNN_NODE_N16_CHUNK_FRAGS 16
+#define CGNN_NODE_N16_CHUNK_BYTES (CGNN_NODE_N16_CHUNK_FRAGS * 3 * 1024)
 
 template <int T, int PFMT>
 __global__ __launch_bounds__(CGNN_NODE_N16_BLOCK) void node_block_x3n16_kernel(
@@ -21,8 +23,10 @@ __global__ __launch_bounds__(CGNN_NODE_N16_BLOCK) void node_block_x3n16_kernel(
     __bf16* __restrict__ pd_next) {
     constexpr int D = 32 * T, OT = 2 * T, KS = T;
     constexpr int M = OT * KS;                                     // fragments per layer
-    constexpr int CH = (M < CGNN_X3_CHUNK_FRAGS) ? M : CGNN_X3_CHUNK_FRAGS;
-    constexpr int NCH = M / CH;
+    constexpr int CH = (M < CGNN_NODE_N16_CHUNK_FRAGS) ? M : CGNN_NODE_N16_CHUNK_FRAGS;
+    constexpr int NCH = M / CH;                                    // 1, 1, 4 for T = 1, 2, 4
+    constexpr int PCH = (M < 16) ? M : 16;                         // projection (one-term bf16) chunks: <= 16 KB
+    constexpr int PNCH = M / PCH;
     constexpr int WAVES = CGNN_NODE_N16_BLOCK / 64;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -39,7 +43,7 @@ __global__ __launch_bounds__(CGNN_NODE_N16_BLOCK) void node_block_x3n16_kernel(
         bend = tiles;
         bstride = (int64_t)nb * WAVES;
     }
-    WeightRing ring(chunks, wave, lane);
+    WeightRingT<CGNN_NODE_N16_CHUNK_BYTES, 2> ring(chunks, wave, lane);
     if (bt < bend) ring.issue(0);
     for (; bt < bend; bt += bstride) {
         const bool more = bt + bstride < bend;
@@ -50,19 +54,19 @@ __global__ __launch_bounds__(CGNN_NODE_N16_BLOCK) void node_block_x3n16_kernel(
         const int64_t rowc = live ? row : n - 1;
         const int foff = 4 * q;                                    // lane's feature offset inside a 16-feature tile
 
-#define CGNN_N16_LAYER(ACC, OP)                                                                       \
-    {                                                                                                 \
-        const LdsWx3 w0(ring.acquire(more));                                                          \
-        dense16x3_part<KS, OT, 0, CH>(ACC, OP, w0, lane);                                             \
-        if (NCH == 2) {                                                                               \
-            const LdsWx3 w1(ring.acquire(more));                                                      \
-            dense16x3_part<KS, OT, (NCH == 2 ? CH : 0), (NCH == 2 ? 2 * CH : CH)>(ACC, OP, w1, lane); \
-        }                                                                                             \
+#define CGNN_N16_CHUNK(ACC, OP, I)                                                                    \
+    if (NCH > I) {                                                                                    \
+        const LdsWx3 w_(ring.acquire(more));                                                          \
+        dense16x3_part<KS, OT, (NCH > I ? I * CH : 0), (NCH > I ? (I + 1) * CH : CH)>(ACC, OP, w_, lane); \
     }
+#define CGNN_N16_LAYER(ACC, OP) \
+    CGNN_N16_CHUNK(ACC, OP, 0) CGNN_N16_CHUNK(ACC, OP, 1) CGNN_N16_CHUNK(ACC, OP, 2) CGNN_N16_CHUNK(ACC, OP, 3)
 
-        f32x4 xv[OT];
+        f32x4 xv[OT], av[OT];      // both row tiles are requested up front: the agg rows arrive under the Wx MFMAs
 #pragma unroll
         for (int o = 0; o < OT; ++o) xv[o] = *reinterpret_cast<const f32x4*>(x + rowc * D + 16 * o + foff);
+#pragma unroll
+        for (int o = 0; o < OT; ++o) av[o] = *reinterpret_cast<const f32x4*>(agg + rowc * D + 16 * o + foff);
         bf16x8 oph[3][KS];
         {
             f32x4 acc[OT];
@@ -73,9 +77,6 @@ __global__ __launch_bounds__(CGNN_NODE_N16_BLOCK) void node_block_x3n16_kernel(
                 CGNN_N16_LAYER(acc, op)
             }
             {
-                f32x4 av[OT];
-#pragma unroll
-                for (int o = 0; o < OT; ++o) av[o] = *reinterpret_cast<const f32x4*>(agg + rowc * D + 16 * o + foff);
                 bf16x8 op[3][KS];
                 operand16x3<false, KS>(op, av);
                 CGNN_N16_LAYER(acc, op)
@@ -92,27 +93,35 @@ __global__ __launch_bounds__(CGNN_NODE_N16_BLOCK) void node_block_x3n16_kernel(
         fill16_global<OT>(out, m.b[m.nh], q);
         CGNN_N16_LAYER(out, oph)
 #undef CGNN_N16_LAYER
+#undef CGNN_N16_CHUNK
         layer_norm16_global<OT>(out, m.gamma, m.beta, q);
 #pragma unroll
         for (int o = 0; o < OT; ++o) {
             if (residual) out[o] += xv[o];
             if (live) *reinterpret_cast<f32x4*>(x_out + row * D + 16 * o + foff) = out[o];
         }
+#define CGNN_N16_PROJ(ACC)                                                                   \
+    {                                                                                            \
+        const LdsW p0_(ring.acquire(more));                                                      \
+        dense16_part<KS, OT, 0, PCH>(ACC, opb, p0_, lane);                                       \
+        if (PNCH == 2) {                                                                         \
+            const LdsW p1_(ring.acquire(more));                                                  \
+            dense16_part<KS, OT, (PNCH == 2 ? PCH : 0), (PNCH == 2 ? 2 * PCH : PCH)>(ACC, opb, p1_, lane); \
+        }                                                                                        \
+    }
         if (ps_next != nullptr) {   // block-uniform: the projection chunks are part of the ring sequence
             bf16x8 opb[KS];
             operand16<false, KS>(opb, out);
             {
                 f32x4 acc[OT];
                 fill16_global<OT>(acc, nullptr, q);
-                const LdsW ws(ring.acquire(more));
-                dense16<KS, OT>(acc, opb, ws, lane);
+                CGNN_N16_PROJ(acc)
                 if (live) store_p16<PFMT, OT>(acc, ps_next, row, q);
             }
             {
                 f32x4 acc[OT];
                 fill16_global<OT>(acc, bd_next, q);
-                const LdsW wd(ring.acquire(more));
-                dense16<KS, OT>(acc, opb, wd, lane);
+                CGNN_N16_PROJ(acc)
                 if (live) store_p16<PFMT, OT>(acc, pd_next, row, q);
             }
         }
@@ -123,7 +132,7 @@ template <int T, int PFMT>
 static int launch(const MlpDev& m, const X3Chunks& ch, const float* b1, const float* x, const float* agg, int64_t n,
                   float* x_out, int residual, const float* bd, void* ps, void* pd, hipStream_t st) {
     auto kern = node_block_x3n16_kernel<T, PFMT>;
-    const int lds = 2 * CGNN_X3_CHUNK_BYTES;
+    const int lds = 2 * CGNN_NODE_N16_CHUNK_BYTES;
     int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                        "hipFuncSetAttribute(node_block_x3n16)");
@@ -141,7 +150,7 @@ int node_block_x3n16(const MlpDev& m, const cgnn_linear* w_x, const cgnn_linear*
     X3Chunks ch;
     memset(&ch, 0, sizeof(ch));
     const int M = 2 * T * T;
-    const int CH = M < CGNN_X3_CHUNK_FRAGS ? M : CGNN_X3_CHUNK_FRAGS;
+    const int CH = M < CGNN_NODE_N16_CHUNK_FRAGS ? M : CGNN_NODE_N16_CHUNK_FRAGS;
     auto add_layer = [&](const void* w) {
         for (int c = 0; c < M / CH; ++c) {
             ch.src[ch.count] = reinterpret_cast<const char*>(w) + (size_t)c * CH * 3072;
@@ -152,10 +161,12 @@ int node_block_x3n16(const MlpDev& m, const cgnn_linear* w_x, const cgnn_linear*
     add_layer(w_agg->w);
     for (int l = 1; l <= m.nh; ++l) add_layer(m.w[l]);
     if (fuse) {
-        ch.src[ch.count] = reinterpret_cast<const char*>(ws_next->w);
-        ch.bytes[ch.count++] = (uint32_t)M * 1024;
-        ch.src[ch.count] = reinterpret_cast<const char*>(wd_next->w);
-        ch.bytes[ch.count++] = (uint32_t)M * 1024;
+        const int PCH = M < 16 ? M : 16;
+        for (const cgnn_linear* L : {ws_next, wd_next})
+            for (int c = 0; c < M / PCH; ++c) {
+                ch.src[ch.count] = reinterpret_cast<const char*>(L->w) + (size_t)c * PCH * 1024;
+                ch.bytes[ch.count++] = (uint32_t)PCH * 1024;
+            }
     }
     const float* b1 = w_x->b ? w_x->b : w_agg->b;
     const float* bd = fuse ? wd_next->b : nullptr;

@@ -19,15 +19,16 @@ struct X3Chunks {
 typedef __attribute__((address_space(3))) void* LdsVoidPtr;
 typedef const __attribute__((address_space(1))) void* GlobalVoidPtr;
 
-struct WeightRing {
+template <int SLOT_BYTES, int SLOTS>
+struct WeightRingT {
     const X3Chunks& c;
     int wave, lane, next;   // next = index of the chunk to be consumed next (its DMA is already in flight)
-    __device__ __forceinline__ WeightRing(const X3Chunks& cc, int w, int l) : c(cc), wave(w), lane(l), next(0) {}
+    __device__ __forceinline__ WeightRingT(const X3Chunks& cc, int w, int l) : c(cc), wave(w), lane(l), next(0) {}
     // every wave copies its share of chunk `idx` (1-KiB pieces wave, wave + #waves, ...) into ring slot idx & 1
     __device__ __forceinline__ void issue(int idx) const {
         const char* src = c.src[idx];
         const uint32_t nb = c.bytes[idx];
-        char* dst = cgnn_smem + (idx & 1) * CGNN_X3_CHUNK_BYTES;
+        char* dst = cgnn_smem + (idx % SLOTS) * SLOT_BYTES;
         const uint32_t step = (blockDim.x >> 6) * 1024u;
         for (uint32_t off = wave * 1024u; off < nb; off += step)
             __builtin_amdgcn_global_load_lds((GlobalVoidPtr)(src + off + lane * 16), (LdsVoidPtr)(dst + off), 16, 0, 0);
@@ -39,8 +40,9 @@ struct WeightRing {
         const int cur = next;
         next = (next + 1 == c.count) ? 0 : next + 1;
         if (next != 0 || more_tiles) issue(next);
-        return (LdsWeightPtr)(cgnn_smem + (cur & 1) * CGNN_X3_CHUNK_BYTES);
+        return (LdsWeightPtr)(cgnn_smem + (cur % SLOTS) * SLOT_BYTES);
     }
 };
+typedef WeightRingT<CGNN_X3_CHUNK_BYTES, 2> WeightRing;
 
 }  // namespace cgnn
