@@ -127,7 +127,8 @@ static int launch_edge_lds(const MlpDev& m, size_t lds, const __bf16* ps, const 
 template <int HT, int DT>
 __global__ __launch_bounds__(CGNN_EDGE_LDS_BLOCK) void edge_block_n16_kernel(
     MlpDev m, const __bf16* __restrict__ ps, const __bf16* __restrict__ pd, const int32_t* __restrict__ src,
-    const int32_t* __restrict__ dst, int64_t num_edges, const float* e_in, float* e_out, float* e_upd, int residual) {
+    const int32_t* __restrict__ dst, int64_t num_edges, const float* e_in, float* e_out, float* e_upd, int residual,
+    const float* __restrict__ x_gather, float* __restrict__ agg_out, int seg_k) {
     stage_weights_to_lds(m, 0);
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     constexpr int D = 32 * DT, DO = 2 * DT, HO = 2 * HT;     // DO / HO: 16-feature tiles
@@ -165,10 +166,31 @@ __global__ __launch_bounds__(CGNN_EDGE_LDS_BLOCK) void edge_block_n16_kernel(
 #pragma unroll
             for (int o = 0; o < DO; ++o) *reinterpret_cast<f32x4*>(e_upd + tbase + n16_tile_offset(o)) = out[o];
         }
+        if (agg_out != nullptr && x_gather == nullptr) {   // message_source "edge": aggregate the update itself
+            const bool writer = (c & (seg_k - 1)) == 0 && e < num_edges;
+#pragma unroll
+            for (int o = 0; o < DO; ++o) {
+                f32x4 g;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) g[i] = seg_k == 16 ? segment_sum<16>(out[o][i]) : segment_sum<8>(out[o][i]);
+                if (writer) *reinterpret_cast<f32x4*>(agg_out + d * D + 16 * o + 4 * q) = g;
+            }
+        }
 #pragma unroll
         for (int o = 0; o < DO; ++o) {
             if (residual) out[o] += ev[o];
             *reinterpret_cast<f32x4*>(e_out + tbase + n16_tile_offset(o)) = out[o];
+        }
+        if (agg_out != nullptr && x_gather != nullptr) {   // PyG default message: aggregate the sender node rows
+            const bool writer = (c & (seg_k - 1)) == 0 && e < num_edges;
+            const float* xr = x_gather + s * D + 4 * q;
+#pragma unroll
+            for (int o = 0; o < DO; ++o) {
+                f32x4 g = *reinterpret_cast<const f32x4*>(xr + 16 * o);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) g[i] = seg_k == 16 ? segment_sum<16>(g[i]) : segment_sum<8>(g[i]);
+                if (writer) *reinterpret_cast<f32x4*>(agg_out + d * D + 16 * o + 4 * q) = g;
+            }
         }
     }
 }
@@ -176,7 +198,7 @@ __global__ __launch_bounds__(CGNN_EDGE_LDS_BLOCK) void edge_block_n16_kernel(
 template <int HT, int DT>
 static int launch_edge_n16(const MlpDev& m, size_t lds, const __bf16* ps, const __bf16* pd, const int32_t* src,
                            const int32_t* dst, int64_t num_edges, const float* e_in, float* e_out, float* e_upd,
-                           int residual, hipStream_t st) {
+                           int residual, const float* x_gather, float* agg_out, int seg_k, hipStream_t st) {
     auto kern = edge_block_n16_kernel<HT, DT>;
     if (lds > 48 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -185,7 +207,8 @@ static int launch_edge_n16(const MlpDev& m, size_t lds, const __bf16* ps, const 
         if (rc != CGNN_OK) return rc;
     }
     const int grid = grid_for_tiles((num_edges + 15) / 16, 1, CGNN_EDGE_LDS_BLOCK / 64);
-    kern<<<grid, CGNN_EDGE_LDS_BLOCK, lds, st>>>(m, ps, pd, src, dst, num_edges, e_in, e_out, e_upd, residual);
+    kern<<<grid, CGNN_EDGE_LDS_BLOCK, lds, st>>>(m, ps, pd, src, dst, num_edges, e_in, e_out, e_upd, residual, x_gather,
+                                                 agg_out, seg_k);
     return check_hip(hipGetLastError(), "cgnn_edge_block(n16) launch");
 }
 
@@ -212,7 +235,8 @@ using namespace cgnn;
 
 extern "C" int cgnn_edge_block(const cgnn_mlp* mlp, const void* ps, const void* pd, const int32_t* src,
                                const int32_t* dst, int64_t num_edges, const float* e_in, float* e_out, float* e_upd,
-                               int32_t residual, int32_t latent, void* stream) {
+                               int32_t residual, int32_t latent, const float* x_gather, float* agg_out,
+                               int32_t seg_k, void* stream) {
     MlpDev m;
     size_t lds = 0;
     int rc = make_mlp_dev(mlp, &m, &lds, "cgnn_edge_block");
@@ -242,6 +266,17 @@ extern "C" int cgnn_edge_block(const cgnn_mlp* mlp, const void* ps, const void* 
     if (num_edges == 0) return CGNN_OK;
     hipStream_t st = (hipStream_t)stream;
     const int HT = hidden / 32, DT = latent / 32, prec = mlp->precision;
+    if (agg_out != nullptr) {
+        if (prec != CGNN_BF16_N16) {
+            set_error("cgnn_edge_block: fused aggregation needs CGNN_BF16_N16 weights (use cgnn_aggregate otherwise)");
+            return CGNN_ERR_UNSUPPORTED;
+        }
+        if ((seg_k != 8 && seg_k != 16) || num_edges % seg_k != 0) {
+            set_error("cgnn_edge_block: fused aggregation needs a fixed in-degree of 8 or 16 (seg_k=%d, E=%lld)", seg_k,
+                      (long long)num_edges);
+            return CGNN_ERR_UNSUPPORTED;
+        }
+    }
     if (prec == CGNN_BF16_N16) {
         if (lds > CGNN_LDS_WEIGHT_BUDGET) {
             set_error("cgnn_edge_block: CGNN_BF16_N16 needs the weights (%zu bytes) resident in LDS", lds);
@@ -249,7 +284,7 @@ extern "C" int cgnn_edge_block(const cgnn_mlp* mlp, const void* ps, const void* 
         }
 #define CGNN_N16(Hh, Dd)      \
     if (HT == Hh && DT == Dd) \
-        return launch_edge_n16<Hh, Dd>(m, lds, (const __bf16*)ps, (const __bf16*)pd, src, dst, num_edges, e_in, e_out, e_upd, residual, st);
+        return launch_edge_n16<Hh, Dd>(m, lds, (const __bf16*)ps, (const __bf16*)pd, src, dst, num_edges, e_in, e_out, e_upd, residual, x_gather, agg_out, seg_k, st);
         CGNN_N16(1, 1) CGNN_N16(2, 2) CGNN_N16(4, 4) CGNN_N16(4, 2)
 #undef CGNN_N16
         set_error("cgnn_edge_block: no CGNN_BF16_N16 kernel for latent=%d hidden=%d", latent, hidden);

@@ -136,6 +136,24 @@ __device__ __forceinline__ void layer_norm16(f32x4 (&a)[OT], LdsVecPtr gamma, Ld
     }
 }
 
+// Sum over the 8 or 16 consecutive lanes of a DPP row that share a receiver (fixed in-degree 8 or 16); every lane
+// of the segment ends up with the total.  Butterfly: quad xor 1, quad xor 2, half-row mirror, row mirror.
+template <int SEG>
+__device__ __forceinline__ float segment_sum(float v) {
+    static_assert(SEG == 8 || SEG == 16, "segments of 8 or 16 lanes");
+    int t = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, t, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    t = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, t, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    t = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, t, 0x141, 0xF, 0xF, true));   // row_half_mirror
+    if (SEG == 16) {
+        t = __builtin_bit_cast(int, v);
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, t, 0x140, 0xF, 0xF, true));  // row_mirror
+    }
+    return v;
+}
+
 // float offset, inside a TILED32 tile, of the 16-byte chunk lane (c, q) owns for 16-feature tile O, for the
 // 16-row half `half` of the tile: feature 16 O + 4 q = 32 t + 8 g + 4 h with t = O >> 1, g = 2 (O & 1) + (q >> 1),
 // h = q & 1; row r = 16 half + c.

@@ -154,11 +154,33 @@ __global__ void aggregate_fixedk_kernel(const float* __restrict__ table, const i
         const int c = (int)(gid - row * chunks);
         const int64_t e0 = row * k;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (k == 16 || k == 8) {
+            // balanced pairwise tree: the order of the cross-lane reduction in the fused edge kernel, so that the
+            // fused and the stand-alone aggregation are bit-identical
+            f32x4 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (j < k) {
+                    const int64_t idx = gather ? (int64_t)gather[e0 + j] : (e0 + j);
+                    v[j] = *reinterpret_cast<const f32x4*>(table + (idx * chunks + c) * 4);
+                } else {
+                    v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) v[j] += v[j + 1];
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) v[j] += v[j + 2];
+#pragma unroll
+            for (int j = 0; j < 16; j += 8) v[j] += v[j + 4];
+            acc = k == 16 ? v[0] + v[8] : v[0];
+        } else {
 #pragma unroll 8
-        for (int j = 0; j < k; ++j) {
-            const int64_t idx = gather ? (int64_t)gather[e0 + j] : (e0 + j);
-            const f32x4 v = *reinterpret_cast<const f32x4*>(table + (idx * chunks + c) * 4);
-            acc += v;
+            for (int j = 0; j < k; ++j) {
+                const int64_t idx = gather ? (int64_t)gather[e0 + j] : (e0 + j);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(table + (idx * chunks + c) * 4);
+                acc += v;
+            }
         }
         *reinterpret_cast<f32x4*>(out + gid * 4) = acc;
     }
@@ -181,8 +203,24 @@ __global__ void aggregate_fixedk_tiled_kernel(const float* __restrict__ table, i
         const int c = (int)(gid - row * chunks);
         const int64_t e0 = row * k;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (k == 16 || k == 8) {   // same balanced tree as above
+            f32x4 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                v[j] = j < k ? *reinterpret_cast<const f32x4*>(table + tiled_chunk_offset(e0 + j, c, chunks))
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 16; j += 2) v[j] += v[j + 1];
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) v[j] += v[j + 2];
+#pragma unroll
+            for (int j = 0; j < 16; j += 8) v[j] += v[j + 4];
+            acc = k == 16 ? v[0] + v[8] : v[0];
+        } else {
 #pragma unroll 8
-        for (int j = 0; j < k; ++j) acc += *reinterpret_cast<const f32x4*>(table + tiled_chunk_offset(e0 + j, c, chunks));
+            for (int j = 0; j < k; ++j)
+                acc += *reinterpret_cast<const f32x4*>(table + tiled_chunk_offset(e0 + j, c, chunks));
+        }
         *reinterpret_cast<f32x4*>(out + gid * 4) = acc;
     }
 }

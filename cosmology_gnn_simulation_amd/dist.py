@@ -25,7 +25,7 @@ from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 
-from . import ops, synthetic
+from . import _lib, ops, synthetic
 
 
 # ----------------------------------------------------------------------------
@@ -238,12 +238,17 @@ class ShardedForward:
         ops.project_nodes(p.ws, None, self.x_all, self.ps, None, p.p_format)    # senders may be ghosts
         ops.project_nodes(None, p.wd, x_own, None, self.pd, p.p_format)         # receivers are owned
         edge_mode = m.message_source == "edge"
-        ops.edge_block(p.edge, self.ps, self.pd, sh.src_local, sh.dst_local, self.el, self.el,
-                       self.e_upd if edge_mode else None, True)
-        if edge_mode:
-            ops.aggregate(self.e_upd, None, sh.dst_local, sh.n_owned, sh.k, sh.src_local.numel(), self.agg)
+        if edge_mode and p.edge.precision == _lib.BF16_N16 and sh.k in (8, 16):   # aggregation folded in
+            ops.edge_block(p.edge, self.ps, self.pd, sh.src_local, sh.dst_local, self.el, self.el, None, True,
+                           agg_out=self.agg, x_gather=None, seg_k=sh.k)
         else:
-            ops.aggregate(self.x_all, sh.src_local, sh.dst_local, sh.n_owned, sh.k, sh.src_local.numel(), self.agg)
+            ops.edge_block(p.edge, self.ps, self.pd, sh.src_local, sh.dst_local, self.el, self.el,
+                           self.e_upd if edge_mode else None, True)
+            if edge_mode:
+                ops.aggregate(self.e_upd, None, sh.dst_local, sh.n_owned, sh.k, sh.src_local.numel(), self.agg)
+            else:
+                ops.aggregate(self.x_all, sh.src_local, sh.dst_local, sh.n_owned, sh.k, sh.src_local.numel(),
+                              self.agg)
         ops.node_block(p.node, p.wx, p.wa, x_own, self.agg, x_own, True)
 
     def decode(self) -> dict:

@@ -258,15 +258,26 @@ def _run_round(p: _PackedProcessor, x: torch.Tensor, e: torch.Tensor, src, dst, 
         ps, pd, agg, e_upd = scratch
     if not projected:
         ps, pd = ops.project_nodes(p.ws, p.wd, x, ps, pd, p.p_format)
-    if message_source == "edge" and e_upd is None:
-        e_upd = e.empty_like()
-    e_new = ops.edge_block(p.edge, ps, pd, src, dst, e, e_out, e_upd if message_source == "edge" else None, residual)
-    if message_source == "x_j":
-        agg = ops.aggregate(x, src, dst, n, fixed_k, src.numel(), agg)
-    elif message_source == "edge":
-        agg = ops.aggregate(e_upd, None, dst, n, fixed_k, src.numel(), agg)
-    else:
+    if message_source not in ("x_j", "edge"):
         raise ValueError(f"message_source must be 'x_j' or 'edge', got {message_source!r}")
+    if message_source == "edge" and p.edge.precision == _lib.BF16_N16 and fixed_k in (8, 16):
+        # the 16-edge kernel folds the aggregation of the edge updates in: one wave tile is exactly one (k=16) or
+        # two (k=8) receivers, so the sum is a cross-lane reduction and the e_upd round trip (2 E D 4 bytes)
+        # disappears.  (Folding the x_j gather in as well measured slower than the stand-alone kernel: +2.0 ms
+        # against 0.7 ms at cfg3 -- its row gathers are better coalesced there.)
+        if agg is None:
+            agg = torch.empty((n, x.shape[1]), dtype=torch.float32, device=x.device)
+        e_new = ops.edge_block(p.edge, ps, pd, src, dst, e, e_out, None, residual, agg_out=agg, x_gather=None,
+                               seg_k=fixed_k)
+    else:
+        if message_source == "edge" and e_upd is None:
+            e_upd = e.empty_like()
+        e_new = ops.edge_block(p.edge, ps, pd, src, dst, e, e_out, e_upd if message_source == "edge" else None,
+                               residual)
+        if message_source == "x_j":
+            agg = ops.aggregate(x, src, dst, n, fixed_k, src.numel(), agg)
+        else:
+            agg = ops.aggregate(e_upd, None, dst, n, fixed_k, src.numel(), agg)
     nxt = None
     if next_round is not None and next_round.p_format == p.p_format and next_round.p_dtype == ps.dtype:
         fused_ok = p.node.precision == _lib.F32X3_N16 and next_round.ws_fused.precision == _lib.BF16_N16

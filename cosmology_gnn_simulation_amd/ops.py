@@ -235,8 +235,11 @@ def project_nodes(ws: Optional[PackedLinear], wd: Optional[PackedLinear], x: tor
 
 def edge_block(mlp: PackedMLP, ps: torch.Tensor, pd: torch.Tensor, src: torch.Tensor, dst: torch.Tensor,
                e_in: TiledRows, e_out: Optional[TiledRows] = None, e_upd: Optional[TiledRows] = None,
-               residual: bool = True) -> TiledRows:
-    """Fused edge update on TILED32 edge latents (``e_out`` may be ``e_in`` for the in-place residual)."""
+               residual: bool = True, agg_out: Optional[torch.Tensor] = None, x_gather: Optional[torch.Tensor] = None,
+               seg_k: int = 0) -> TiledRows:
+    """Fused edge update on TILED32 edge latents (``e_out`` may be ``e_in`` for the in-place residual).
+    ``agg_out`` (N16 kernels, fixed in-degree ``seg_k`` in {8, 16}): also write the receivers' aggregate -- of the
+    sender rows ``x_gather[src]`` when given (PyG's default message), else of the edge update itself."""
     if not isinstance(e_in, TiledRows):
         raise CgnnError("edge_block: edge latents must be TiledRows (use ops.relayout / TiledRows.from_rows)")
     src, dst = i32c(src, "src"), i32c(dst, "dst")
@@ -252,11 +255,19 @@ def edge_block(mlp: PackedMLP, ps: torch.Tensor, pd: torch.Tensor, src: torch.Te
             raise CgnnError("edge_block: e_out / e_upd do not match the edge latents")
     if src.numel() != ne or dst.numel() != ne:
         raise CgnnError("edge_block: src/dst length does not match the edge latents")
+    if agg_out is not None:
+        if x_gather is not None:
+            x_gather = f32c(x_gather, "x_gather")
+            if x_gather.shape[1] != latent:
+                raise CgnnError("edge_block: x_gather width must equal the latent size")
+        if agg_out.dtype != torch.float32 or not agg_out.is_contiguous() or agg_out.shape[1] != latent:
+            raise CgnnError("edge_block: agg_out must be contiguous float32 [receivers, latent]")
     with _timed("edge_block", e_in.device):
         check(_lib.load().cgnn_edge_block(C.byref(mlp.struct()), ps.data_ptr(), pd.data_ptr(), src.data_ptr(),
                                           dst.data_ptr(), ne, e_in.buf.data_ptr(), e_out.buf.data_ptr(),
                                           None if e_upd is None else e_upd.buf.data_ptr(),
-                                          1 if residual else 0, latent, stream_ptr(e_in.device)), "cgnn_edge_block")
+                                          1 if residual else 0, latent, ptr(x_gather), ptr(agg_out), seg_k,
+                                          stream_ptr(e_in.device)), "cgnn_edge_block")
     return e_out
 
 

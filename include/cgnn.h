@@ -138,11 +138,18 @@ int cgnn_project_nodes(const cgnn_linear* ws, const cgnn_linear* wd, int32_t pre
  * with the first layer evaluated as ps[src] + pd[dst] + e_in * We^T.
  * mlp->layer[0] holds We (in_dim = D); e_out may alias e_in.
  * e_in / e_out / e_upd are CGNN_TILED32 buffers of cgnn_tiled_rows(num_edges) rows;
- * ps / pd are cgnn_project_nodes tables in the cgnn_ptable format matching mlp->precision. */
+ * ps / pd are cgnn_project_nodes tables in the cgnn_ptable format matching mlp->precision.
+ *
+ * Optional fused aggregation (agg_out != NULL; CGNN_BF16_N16 kernels, receiver-sorted edges with
+ * fixed in-degree seg_k in {8, 16}): the same launch also writes the receivers' aggregate
+ *   agg_out[i] = sum_{e: dst[e]==i} x_gather[src[e]]     (x_gather != NULL: PyG's default message)
+ *   agg_out[i] = sum_{e: dst[e]==i} u[e]                 (x_gather == NULL: message_source "edge")
+ * i.e. cgnn_aggregate folded in (graph_network.py:92): a 16-edge wave tile is exactly one (k=16) or two
+ * (k=8) receivers, so the sum is a cross-lane reduction and the e_upd round trip disappears. */
 int cgnn_edge_block(const cgnn_mlp* mlp, const void* ps, const void* pd,
                     const int32_t* src, const int32_t* dst, int64_t num_edges,
                     const float* e_in, float* e_out, float* e_upd, int32_t residual,
-                    int32_t latent, void* stream);
+                    int32_t latent, const float* x_gather, float* agg_out, int32_t seg_k, void* stream);
 
 /* ---- K7: aggregation (PyG propagate, aggr='add') ------------------------------
  * out[i] = sum over edges e with dst[e]==i of table[gather ? gather[e] : e].

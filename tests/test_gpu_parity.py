@@ -56,6 +56,21 @@ def test_mlp_rows(n, fin, hid, out, nh, ln, prec, tol):
     assert rel_l2(got, want) <= tol
 
 
+def _kernel_order_sum(rows):
+    """[n, k, width] -> [n, width] in the kernels' order: a balanced pairwise tree for k in {8, 16} (the order of the
+    cross-lane reduction fused into the edge kernel), sequential otherwise."""
+    n, k, _ = rows.shape
+    if k in (8, 16):
+        v = rows
+        while v.shape[1] > 1:
+            v = v[:, 0::2] + v[:, 1::2]
+        return v[:, 0]
+    out = rows[:, 0].clone()
+    for j in range(1, k):
+        out += rows[:, j]
+    return out
+
+
 @pytest.mark.parametrize("n,k,width", [(1000, 16, 128), (77, 8, 64), (5, 32, 256), (300, 3, 32)])
 def test_aggregate_fixed_k_is_exact_segment_sum(n, k, width):
     gen = torch.Generator().manual_seed(n)
@@ -63,11 +78,7 @@ def test_aggregate_fixed_k_is_exact_segment_sum(n, k, width):
     src = torch.randint(0, n, (n * k,), generator=gen)
     dst = torch.arange(n).repeat_interleave(k)
     got = ops.aggregate(x.to(DEV), src.to(DEV), None, n, fixed_k=k).cpu()
-    # same summation order as the kernel (j ascending): bit exact
-    want = torch.zeros(n, width)
-    for j in range(k):
-        want += x[src.view(n, k)[:, j]]
-    assert torch.equal(got, want)
+    assert torch.equal(got, _kernel_order_sum(x[src].view(n, k, width)))   # same summation order: bit exact
     ref = cpu_ref.propagate_add(x, torch.stack([src, dst]))
     assert rel_err(got, ref) <= 1e-6
 
@@ -166,9 +177,7 @@ def test_aggregate_tiled_messages(n, k, width):
     msg = torch.randn(n * k, width, generator=gen)
     dst = torch.arange(n).repeat_interleave(k)
     t = ops.TiledRows.from_rows(msg.to(DEV))
-    want = msg.view(n, k, width)[:, 0].clone()
-    for j in range(1, k):
-        want += msg.view(n, k, width)[:, j]
+    want = _kernel_order_sum(msg.view(n, k, width))
     assert torch.equal(ops.aggregate(t, None, None, n, fixed_k=k).cpu(), want)
     got = ops.aggregate(t, None, dst.to(DEV), n, fixed_k=0).cpu()          # general path on the tiled table
     assert torch.allclose(got, want, rtol=0, atol=1e-5 * float(want.abs().max()))
@@ -201,6 +210,32 @@ def test_edge_block_kernel_variants(fmt, tol, n, k, d):
     got = ops.edge_block(mlp, ps, pd, dev(src), dev(dst), et, None, upd, True)
     assert rel_l2(got.to_rows().cpu(), want) <= tol
     assert rel_l2((got.to_rows() - upd.to_rows()).cpu(), e) <= 1e-6      # e_out - e_upd == e_in (f32 residual)
+
+
+@pytest.mark.parametrize("n,k,d,mode", [(500, 16, 128, "x_j"), (333, 8, 64, "x_j"), (500, 16, 64, "edge"), (77, 8, 32, "edge")])
+def test_fused_aggregation_in_edge_kernel_is_bit_identical(n, k, d, mode):
+    """cgnn_edge_block's fused aggregate (cross-lane reduction) == the stand-alone cgnn_aggregate, bit for bit."""
+    gen = torch.Generator().manual_seed(n + k)
+    E = n * k
+    x = torch.randn(n, d, generator=gen).to(DEV)
+    e = ops.TiledRows.from_rows(torch.randn(E, d, generator=gen).to(DEV))
+    src = torch.randint(0, n, (E,), generator=gen).int().to(DEV)
+    dst = torch.arange(n).repeat_interleave(k).int().to(DEV)
+    w = lambda o, i: ((torch.rand(o, i, generator=gen) * 2 - 1) / i ** 0.5).to(DEV)  # noqa: E731
+    b = lambda o: (torch.rand(o, generator=gen) - 0.5).to(DEV)                        # noqa: E731
+    w1, b1 = w(d, 3 * d), b(d)
+    mlp = ops.PackedMLP([(w1, b1), (w(d, d), b(d)), (w(d, d), b(d))], (1 + 0.1 * b(d), 0.1 * b(d)), "bf16_n16",
+                        first_layer_cols=(2 * d, d))
+    ws, wd = ops.PackedLinear(w1, None, "bf16", 0, d), ops.PackedLinear(w1, b1, "bf16", d, d)
+    ps, pd = ops.project_nodes(ws, wd, x, None, None, ops.p_table_format(mlp.precision))
+    upd = e.empty_like()
+    out_a = ops.edge_block(mlp, ps, pd, src, dst, e, None, upd, True)
+    want = ops.aggregate(x, src, dst, n, k) if mode == "x_j" else ops.aggregate(upd, None, dst, n, k)
+    agg = torch.full((n, d), float("nan"), device=DEV)
+    out_b = ops.edge_block(mlp, ps, pd, src, dst, e, None, None, True, agg_out=agg,
+                           x_gather=x if mode == "x_j" else None, seg_k=k)
+    assert torch.equal(out_a.to_rows(), out_b.to_rows())
+    assert torch.equal(agg, want)
 
 
 # ------------------------------------------------------------------ blocks and model vs golden
