@@ -156,24 +156,20 @@ __global__ void aggregate_fixedk_kernel(const float* __restrict__ table, const i
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (k == 16 || k == 8) {
             // balanced pairwise tree: the order of the cross-lane reduction in the fused edge kernel, so that the
-            // fused and the stand-alone aggregation are bit-identical
-            f32x4 v[16];
+            // fused and the stand-alone aggregation are bit-identical.  Eight rows at a time keeps 8 loads in flight.
+            f32x4 half[2];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if (j < k) {
-                    const int64_t idx = gather ? (int64_t)gather[e0 + j] : (e0 + j);
+            for (int hh = 0; hh < 2; ++hh) {
+                if (8 * hh >= k) break;
+                f32x4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int64_t idx = gather ? (int64_t)gather[e0 + 8 * hh + j] : (e0 + 8 * hh + j);
                     v[j] = *reinterpret_cast<const f32x4*>(table + (idx * chunks + c) * 4);
-                } else {
-                    v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+                half[hh] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
             }
-#pragma unroll
-            for (int j = 0; j < 16; j += 2) v[j] += v[j + 1];
-#pragma unroll
-            for (int j = 0; j < 16; j += 4) v[j] += v[j + 2];
-#pragma unroll
-            for (int j = 0; j < 16; j += 8) v[j] += v[j + 4];
-            acc = k == 16 ? v[0] + v[8] : v[0];
+            acc = k == 16 ? half[0] + half[1] : half[0];
         } else {
 #pragma unroll 8
             for (int j = 0; j < k; ++j) {
@@ -204,18 +200,17 @@ __global__ void aggregate_fixedk_tiled_kernel(const float* __restrict__ table, i
         const int64_t e0 = row * k;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (k == 16 || k == 8) {   // same balanced tree as above
-            f32x4 v[16];
+            f32x4 half[2];
 #pragma unroll
-            for (int j = 0; j < 16; ++j)
-                v[j] = j < k ? *reinterpret_cast<const f32x4*>(table + tiled_chunk_offset(e0 + j, c, chunks))
-                             : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int hh = 0; hh < 2; ++hh) {
+                if (8 * hh >= k) break;
+                f32x4 v[8];
 #pragma unroll
-            for (int j = 0; j < 16; j += 2) v[j] += v[j + 1];
-#pragma unroll
-            for (int j = 0; j < 16; j += 4) v[j] += v[j + 2];
-#pragma unroll
-            for (int j = 0; j < 16; j += 8) v[j] += v[j + 4];
-            acc = k == 16 ? v[0] + v[8] : v[0];
+                for (int j = 0; j < 8; ++j)
+                    v[j] = *reinterpret_cast<const f32x4*>(table + tiled_chunk_offset(e0 + 8 * hh + j, c, chunks));
+                half[hh] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+            acc = k == 16 ? half[0] + half[1] : half[0];
         } else {
 #pragma unroll 8
             for (int j = 0; j < k; ++j)
