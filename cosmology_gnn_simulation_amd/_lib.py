@@ -27,7 +27,7 @@ EXPORTS = (
     "cgnn_version", "cgnn_arch", "cgnn_last_error", "cgnn_packed_linear_bytes", "cgnn_pack_linear",
     "cgnn_mlp_rows", "cgnn_project_nodes", "cgnn_edge_block", "cgnn_aggregate", "cgnn_node_block",
     "cgnn_knn_workspace_bytes", "cgnn_knn_periodic", "cgnn_knn_sorted_order", "cgnn_segment_colsum",
-    "cgnn_gather_rows", "cgnn_scatter_rows", "cgnn_tiled_rows", "cgnn_relayout",
+    "cgnn_gather_rows", "cgnn_scatter_rows", "cgnn_tiled_rows", "cgnn_relayout", "cgnn_window_features",
 )
 ROWS, TILED32 = 0, 1
 
@@ -81,6 +81,7 @@ def load() -> C.CDLL:
     lib.cgnn_knn_periodic.argtypes = [vp, i64, f32, i32, vp, i64, vp, vp, vp, sz, vp]
     lib.cgnn_knn_sorted_order.argtypes = [vp, i64, vp, vp]
     lib.cgnn_segment_colsum.argtypes = [vp, vp, i64, i32, i32, vp, vp]
+    lib.cgnn_window_features.argtypes = [vp, vp, vp, vp, i32, i64, f32, f32, f32, f32, f32, f32, vp, vp, vp]
     lib.cgnn_gather_rows.argtypes = [vp, vp, i64, i32, vp, vp]
     lib.cgnn_scatter_rows.argtypes = [vp, vp, i64, i32, vp, vp]
     for name in EXPORTS:

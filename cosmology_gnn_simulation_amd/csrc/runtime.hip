@@ -318,6 +318,52 @@ __global__ void scatter_rows_scalar_kernel(const float* __restrict__ rows, const
     }
 }
 
+// ------------------------------------------------------------------ window features
+__device__ __forceinline__ float torch_remainder(float a, float b) {   // torch.remainder for float32
+    float r = fmodf(a, b);
+    if (r != 0.f && ((r < 0.f) != (b < 0.f))) r = __fadd_rn(r, b);
+    return r;
+}
+
+__global__ void window_features_kernel(const float* __restrict__ pos_seq, const float* __restrict__ temp_seq,
+                                       const float* __restrict__ pos_noise, const float* __restrict__ temp_noise,
+                                       int W, int64_t n, float box, float dt, float vel_mean, float vel_std,
+                                       float temp_mean, float temp_std, float* __restrict__ x,
+                                       float* __restrict__ recent_pos) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int F = 3 * (W - 1) + W;
+    const float half = box * 0.5f, nhalf = -half;
+    float* xr = x + i * F;
+    float prev[3];
+    for (int t = 0; t < W; ++t) {
+        float cur[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float p = pos_seq[((int64_t)t * n + i) * 3 + c];
+            if (pos_noise != nullptr) p = __fadd_rn(p, pos_noise[(i * W + t) * 3 + c]);
+            cur[c] = torch_remainder(p, box);
+        }
+        if (t > 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float d = __fsub_rn(cur[c], prev[c]);
+                if (d < nhalf) d = __fadd_rn(d, box);
+                if (d > half) d = __fsub_rn(d, box);
+                const float v = __fdiv_rn(d, dt);
+                xr[3 * (t - 1) + c] = __fdiv_rn(__fsub_rn(v, vel_mean), vel_std);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) prev[c] = cur[c];
+        float T = temp_seq[(int64_t)t * n + i];
+        if (temp_noise != nullptr) T = __fadd_rn(T, temp_noise[i * W + t]);
+        xr[3 * (W - 1) + t] = __fdiv_rn(__fsub_rn(T, temp_mean), temp_std);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) recent_pos[i * 3 + c] = prev[c];
+}
+
 // ------------------------------------------------------------------ momentum
 // Each block owns a contiguous run of rows.  Runs inside one graph are reduced in
 // double precision in LDS and flushed with one atomic per column.
@@ -519,6 +565,21 @@ int cgnn_scatter_rows(const float* rows, const int32_t* idx, int64_t n_idx, int3
         scatter_rows_scalar_kernel<<<blocks_for(n_idx * width, 32), CGNN_BLOCK, 0, st>>>(rows, idx, n_idx, width,
                                                                                      table);
     return check_hip(hipGetLastError(), "cgnn_scatter_rows launch");
+}
+
+int cgnn_window_features(const float* pos_seq, const float* temp_seq, const float* pos_noise, const float* temp_noise,
+                         int32_t window, int64_t n, float box_size, float dt, float vel_mean, float vel_std,
+                         float temp_mean, float temp_std, float* x, float* recent_pos, void* stream) {
+    if (!pos_seq || !temp_seq || !x || !recent_pos || window < 2 || n < 0 || !(box_size > 0.f) || dt == 0.f ||
+        vel_std == 0.f || temp_std == 0.f) {
+        set_error("cgnn_window_features: invalid argument");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if (n == 0) return CGNN_OK;
+    window_features_kernel<<<(unsigned)((n + CGNN_BLOCK - 1) / CGNN_BLOCK), CGNN_BLOCK, 0, (hipStream_t)stream>>>(
+        pos_seq, temp_seq, pos_noise, temp_noise, window, n, box_size, dt, vel_mean, vel_std, temp_mean, temp_std, x,
+        recent_pos);
+    return check_hip(hipGetLastError(), "cgnn_window_features launch");
 }
 
 int cgnn_segment_colsum(const float* acc, const int32_t* batch, int64_t n, int32_t width, int32_t num_graphs,

@@ -4,14 +4,16 @@
 attributes (reference data_utils.py:72-228) but builds the periodic k-NN graph and
 its edge features on the GPU (``cgnn_knn_periodic``) instead of running
 ``torch_cluster.knn`` over a 27x ghost-extended copy on one CPU thread
-(:148-164).  The cheap O(N W) feature/target arithmetic (:78-145,166-214) is
-restated with torch element-wise ops on the device.
+(:148-164), and the node features in one kernel.  Only the training targets
+(:166-214, used by ``train.py`` alone) stay torch element-wise expressions.
 
 Faithfulness notes
 * random-walk noise is drawn on the CPU with the reference's exact call sequence
   (``randn_like`` on ``[N, W-1, 3]`` then ``[N, W-1, 1]``, even when
   ``noise_std == 0``, :47,:63), so seeded runs see the same noise and the same RNG
   stream afterwards;
+* node features (wrap, velocities, normalisation: :91-145) come from one HIP kernel
+  (``cgnn_window_features``) with the reference's float32 operation order;
 * edge displacements use the un-shifted sender (not minimum-image), as :151-164 do;
 * the graph is receiver-sorted with ``num_neighbors`` edges per receiver, the
   receiver itself first (distance 0).
@@ -133,18 +135,22 @@ def preprocess(position_seq, temperature_seq, metadata, target_position=None, ta
         trs_cpu = torch.tensor(metadata["temp_rate_std"], dtype=torch.float32)
         pos_noise_cpu, tmp_noise_cpu = _draw_reference_noise(pos_seq, tmp_seq, noise_std, trs_cpu, dt, box_size)
 
-    pos_seq = pos_seq.to(device)
+    pos_seq = pos_seq.to(device)                                          # [N, W, 3] view of the [W, N, 3] window
     tmp_seq = tmp_seq.to(device)
+    pos_noise = tmp_noise = None
     if noise_std != 0.0:
-        pos_noise = pos_noise_cpu.to(device)
-        pos_seq = torch.remainder(pos_seq + pos_noise, box_size)
-        tmp_seq = tmp_seq + tmp_noise_cpu.to(device)
-    else:  # the noise is exactly zero: x + 0 == x, skip the transfers
-        pos_seq = torch.remainder(pos_seq, box_size)
+        pos_noise, tmp_noise = pos_noise_cpu.to(device), tmp_noise_cpu.to(device)
 
-    recent_position = pos_seq[:, -1].contiguous()
-    velocity_seq = _wrap_displacement(pos_seq[:, 1:] - pos_seq[:, :-1], box_size) / dt
-    recent_temperature = tmp_seq[:, -1]
+    # --- node features and the wrapped last frame in one kernel (cgnn_window_features) ---
+    node_features, recent_position = ops.window_features(pos_seq.permute(1, 0, 2), tmp_seq.permute(1, 0, 2), metadata, dt,
+                                                         box_size, pos_noise, tmp_noise)
+
+    velocity_seq = recent_temperature = None
+    if target_position is not None or target_temperature is not None:
+        # training targets (reference :166-214): the same element-wise expressions, on the device
+        wp = torch.remainder(pos_seq + pos_noise, box_size) if noise_std != 0.0 else torch.remainder(pos_seq, box_size)
+        velocity_seq = _wrap_displacement(wp[:, 1:] - wp[:, :-1], box_size) / dt
+        recent_temperature = (tmp_seq + tmp_noise if noise_std != 0.0 else tmp_seq)[:, -1]
 
     if target_temperature is not None:
         target_temperature = target_temperature.float()
@@ -155,11 +161,6 @@ def preprocess(position_seq, temperature_seq, metadata, target_position=None, ta
         if target_temperature.shape != recent_temperature.shape and \
                 target_temperature.numel() == recent_temperature.numel():
             target_temperature = target_temperature.reshape(recent_temperature.shape)
-
-    # --- node features: normalised velocities (time-major, then xyz) and temperatures ---
-    nvel = (velocity_seq - _meta(metadata, "vel_mean", device)) / _meta(metadata, "vel_std", device)
-    ntmp = (tmp_seq - _meta(metadata, "temp_mean", device)) / _meta(metadata, "temp_std", device)
-    node_features = torch.cat((nvel.reshape(nvel.size(0), -1), ntmp.reshape(ntmp.size(0), -1)), dim=-1)
 
     # --- periodic k-NN graph + edge features on the device ---
     edge_index, edge_attr, senders, order = knn_graph_periodic(recent_position, box_size, int(num_neighbors),

@@ -273,7 +273,6 @@ class ShardedForward:
 
 def build_synthetic_shard(particles_per_gpu: int, world: int, rank: int, k: int, seed: int, device, metadata: dict,
                           group=None) -> Shard:
-    from .data_utils import preprocess  # noqa: F401  (feature arithmetic is shared with the single-GPU path)
     n_total = particles_per_gpu * world
     snap = synthetic.make_snapshot(n_total, seed=seed)
     box, dt = metadata["box_size"], metadata["dt"]
@@ -283,13 +282,6 @@ def build_synthetic_shard(particles_per_gpu: int, world: int, rank: int, k: int,
     sh = build_shard(pos, box, k, world, rank)
     sh = exchange_requests(sh, group)
     own = sh.owned_global
-    # node features of the owned particles: same arithmetic as data_utils.preprocess (noise_std = 0)
-    pseq = torch.remainder(coords[:, own].permute(1, 0, 2), box)
-    d = pseq[:, 1:] - pseq[:, :-1]
-    half = box / 2
-    d = torch.where(d < -half, d + box, d)
-    d = torch.where(d > half, d - box, d)
-    vel = (d / dt - metadata["vel_mean"]) / metadata["vel_std"]
-    tmp = (energy[:, own].permute(1, 0, 2) - metadata["temp_mean"]) / metadata["temp_std"]
-    sh.x_feat = torch.cat((vel.reshape(vel.size(0), -1), tmp.reshape(tmp.size(0), -1)), dim=-1).float().contiguous()
+    # node features of the owned particles: the same kernel data_utils.preprocess uses
+    sh.x_feat, _ = ops.window_features(coords[:, own].contiguous(), energy[:, own].contiguous(), metadata, dt, box)
     return sh

@@ -349,6 +349,36 @@ def knn_periodic(pos: torch.Tensor, box_size: float, k: int, query_ids: Optional
     return senders, edge_attr, order
 
 
+def window_features(pos_seq: torch.Tensor, temp_seq: torch.Tensor, metadata: dict, dt: float, box_size: float,
+                    pos_noise: Optional[torch.Tensor] = None, temp_noise: Optional[torch.Tensor] = None):
+    """``[W, N, 3]`` positions and ``[W, N(, 1)]`` temperatures -> ``(x [N, 3(W-1)+W], recent_pos [N, 3])``
+    (reference data_utils.py:91-145 in one kernel).  Scalar metadata only (the reference's generator writes
+    per-feature lists of length 1 for temperature, which are accepted)."""
+    def scalar(v):
+        t = torch.as_tensor(v, dtype=torch.float32).reshape(-1)
+        if t.numel() != 1:
+            raise CgnnError("window_features: metadata statistics must be scalars")
+        return float(t[0])
+    pos_seq = f32c(pos_seq, "position window")
+    temp_seq = f32c(temp_seq, "temperature window")
+    w, n = pos_seq.shape[0], pos_seq.shape[1]
+    if pos_seq.shape != (w, n, 3) or temp_seq.numel() != w * n:
+        raise CgnnError(f"window_features: expected [W, N, 3] and [W, N(, 1)], got {tuple(pos_seq.shape)} / "
+                        f"{tuple(temp_seq.shape)}")
+    if pos_noise is not None:
+        pos_noise, temp_noise = f32c(pos_noise, "position noise"), f32c(temp_noise, "temperature noise")
+        if pos_noise.shape != (n, w, 3) or temp_noise.numel() != n * w:
+            raise CgnnError("window_features: noise must be [N, W, 3] / [N, W(, 1)]")
+    x = torch.empty((n, 3 * (w - 1) + w), dtype=torch.float32, device=pos_seq.device)
+    recent = torch.empty((n, 3), dtype=torch.float32, device=pos_seq.device)
+    check(_lib.load().cgnn_window_features(pos_seq.data_ptr(), temp_seq.data_ptr(), ptr(pos_noise), ptr(temp_noise), w, n,
+                                           float(box_size), float(dt), scalar(metadata["vel_mean"]),
+                                           scalar(metadata["vel_std"]), scalar(metadata["temp_mean"]),
+                                           scalar(metadata["temp_std"]), x.data_ptr(), recent.data_ptr(),
+                                           stream_ptr(pos_seq.device)), "cgnn_window_features")
+    return x, recent
+
+
 def segment_colsum(acc: torch.Tensor, batch: Optional[torch.Tensor], num_graphs: int) -> torch.Tensor:
     acc = f32c(acc, "acc")
     if batch is not None:

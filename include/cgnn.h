@@ -198,6 +198,18 @@ int cgnn_knn_periodic(const float* pos, int64_t n, float box_size, int32_t k,
  * index of the i-th particle in sorted order. */
 int cgnn_knn_sorted_order(const void* workspace, int64_t n, int32_t* perm, void* stream);
 
+/* ---- window -> node features (reference data_utils.py:91-92, :100-107, :127-145) -------------------
+ * pos_seq [W, N, 3] and temp_seq [W, N] (frame-major, as the drivers hold a window), optional additive
+ * noise pos_noise [N, W, 3] / temp_noise [N, W] (NULL = none).  Writes
+ *   x[n, 3t + c]      = ((wrap(p[t+1] - p[t]) / dt) - vel_mean) / vel_std,   t < W-1   (p = remainder(pos + noise, box))
+ *   x[n, 3(W-1) + t]  = ((temp[t] + noise) - temp_mean) / temp_std,          t < W
+ *   recent_pos[n, :]  = p[W-1]
+ * with wrap(d) = d + box if d < -box/2, then d - box if d > box/2: float32, one rounding per operation, the
+ * order of the reference's tensor expressions. */
+int cgnn_window_features(const float* pos_seq, const float* temp_seq, const float* pos_noise, const float* temp_noise,
+                         int32_t window, int64_t n, float box_size, float dt, float vel_mean, float vel_std,
+                         float temp_mean, float temp_std, float* x, float* recent_pos, void* stream);
+
 /* ---- K11: momentum-conservation term ------------------------------------------
  * sums[g, c] = sum_{i: batch[i]==g} acc[i, c] in float64 (batch sorted ascending,
  * NULL = one graph); reference train.py:107-118.  sums is [num_graphs, width] f64,

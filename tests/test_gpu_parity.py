@@ -339,7 +339,7 @@ def test_preprocess_vs_reference_fixture(golden):
                               meta["dt"], meta["box_size"])
     assert torch.equal(d.edge_index.cpu(), edge_index_from(g))               # bit exact
     assert torch.equal(d.pos.cpu(), torch.from_numpy(g["pos"]))
-    assert torch.allclose(d.x.cpu(), torch.from_numpy(g["x"]), rtol=0, atol=1e-6)
+    assert torch.equal(d.x.cpu(), torch.from_numpy(g["x"]))                  # one rounding per op, same order
     assert torch.allclose(d.edge_attr.cpu(), torch.from_numpy(g["edge_attr"]), rtol=0, atol=1e-6 * meta["box_size"])
     assert torch.allclose(d.y_acc.cpu(), torch.from_numpy(g["y_acc"]), rtol=1e-6, atol=1e-4)
     assert torch.allclose(d.y_temp_rate.cpu(), torch.from_numpy(g["y_temp_rate"]), rtol=1e-6, atol=1e-5)
@@ -424,3 +424,29 @@ def test_on_device_rollout_matches_restatement():
     assert torch.allclose(got["InternalEnergy"].cpu(), want["InternalEnergy"], rtol=0, atol=1e-5)
     err = ro.calculate_errors(got, snap)
     assert len(err["position_errors"]) == Wr + 3 and err["position_errors"][0] == 0.0
+
+
+@pytest.mark.parametrize("d,h,k,nh,L,edge_prec,node_prec", [(256, 256, 32, 2, 2, "bf16", "fp32x3"),      # cfg5 shape
+                                                          (256, 256, 8, 2, 1, "fp32", "fp32"),
+                                                          (64, 128, 8, 2, 2, "bf16", "fp32"),           # hidden != latent
+                                                          (256, 128, 16, 1, 2, "fp32", "fp32x3"),
+                                                          (128, 128, 16, 3, 2, "bf16", "fp32x3")])      # 3 hidden layers
+def test_model_other_shapes_vs_oracle(d, h, k, nh, L, edge_prec, node_prec):
+    """Shapes beyond the committed fixtures (README.md:59-62 ranges; BASELINE cfg5 = latent 256, k 32): the HIP
+    forward against the oracle on a fresh graph."""
+    n = 300
+    snap = synthetic.make_snapshot(n, seed=61 + d + k)
+    meta = synthetic.make_metadata()
+    g = data_utils.preprocess(snap["Coordinates"][:W], snap["InternalEnergy"][:W], meta, None, None, 0.0, k, 0.01, 1.0)
+    sd = synthetic.make_state_dict(d, h, nh, L, 3)
+    m = graph_network.EncodeProcessDecode(d, h, nh, L, 3)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    m.edge_precision, m.node_precision = edge_prec, node_prec
+    with torch.no_grad():
+        out = m.forward_with_latents(g)
+        ref = cpu_ref.encode_process_decode(sd, g.x.cpu(), g.edge_index.cpu(), g.edge_attr.cpu(), nh, L,
+                                            return_latents=True)
+    assert rel_err(out["acceleration"].cpu(), ref["acceleration"]) <= TOL
+    assert rel_err(out["temp_rate"].cpu(), ref["temp_rate"]) <= TOL
+    assert rel_l2(out["edge_latent"].cpu(), ref["edge_latent"]) <= (3e-2 if edge_prec == "bf16" else TOL)
