@@ -56,6 +56,8 @@ def parse_args():
     p.add_argument("--seed", type=int, default=1236)   # 1234 + cfg index 2
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="process-group backend for --gpus > 1 (gloo = single-GPU rehearsal, staged through the host)")
+    p.add_argument("--hip-graph", action="store_true",
+                   help="replay the forward from a captured HIP graph (launch-bound sizes; single GPU)")
     p.add_argument("--check", action="store_true",
                    help="N > 1: also run the unsharded forward on rank 0 and compare (small sizes only)")
     return p.parse_args()
@@ -154,6 +156,9 @@ def main():
         knn_ms = tm.summary()["knn_periodic"][1]
         n_local, e_local = graph.x.shape[0], graph.edge_index.shape[1]
         run = lambda: model(graph)  # noqa: E731
+        if args.hip_graph:
+            from cosmology_gnn_simulation_amd.graphed import GraphedForward
+            run = GraphedForward(model, graph)
     else:
         sharded = dist_ctx.build_synthetic_shard(args.particles, world, rank, k, args.seed, dev, meta)
         torch.cuda.synchronize()
@@ -199,6 +204,8 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel (the fused edge block), from HIP events in the timed region ----
+        if "edge_block" not in per_op:      # HIP-graph replay: launches are inside the graph, no per-op events
+            per_op = {"edge_block": (1, float("nan"))}
         calls, total_ms = per_op["edge_block"]
         edge_ms = total_ms / calls
         sz_w = 2 if args.edge_precision == "bf16" else 4

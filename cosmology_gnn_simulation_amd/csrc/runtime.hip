@@ -145,11 +145,32 @@ __global__ void pack_f32x3_n16_kernel(const float* __restrict__ w, int out_dim, 
 // ------------------------------------------------------------------ aggregation
 // Fixed in-degree, receiver-sorted: one (row, 16-byte chunk) per thread; the k
 // neighbour rows are read with 16 B per lane, a row's chunks on adjacent lanes.
+// XCD-aware work split for the gather kernels: workgroup b runs on XCD b % 8 (round-robin dispatch), so the
+// workgroups of one XCD take one contiguous eighth of the (spatially ordered) receivers and the sender rows they
+// share are fetched into that XCD's L2 once instead of into all eight.
+struct WorkRange {
+    int64_t first, end, stride;
+};
+__device__ __forceinline__ WorkRange xcd_work_range(int64_t total) {
+    const int nb = gridDim.x, b = blockIdx.x;
+    WorkRange r;
+    if ((nb & 7) == 0) {
+        const int xcd = b & 7, slot = b >> 3, per = nb >> 3;
+        r.first = total * xcd / 8 + (int64_t)slot * blockDim.x + threadIdx.x;
+        r.end = total * (xcd + 1) / 8;
+        r.stride = (int64_t)per * blockDim.x;
+    } else {
+        r.first = (int64_t)b * blockDim.x + threadIdx.x;
+        r.end = total;
+        r.stride = (int64_t)nb * blockDim.x;
+    }
+    return r;
+}
+
 __global__ void aggregate_fixedk_kernel(const float* __restrict__ table, const int32_t* __restrict__ gather,
                                         int k, int64_t num_nodes, int chunks, float* __restrict__ out) {
-    const int64_t total = num_nodes * chunks;
-    for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total;
-         gid += (int64_t)gridDim.x * blockDim.x) {
+    const WorkRange wr = xcd_work_range(num_nodes * chunks);
+    for (int64_t gid = wr.first; gid < wr.end; gid += wr.stride) {
         const int64_t row = gid / chunks;
         const int c = (int)(gid - row * chunks);
         const int64_t e0 = row * k;
@@ -404,6 +425,15 @@ static inline int blocks_for(int64_t total, int cap_mult = 16) {
     return (int)b;
 }
 
+// grid for the XCD-aware kernels: a multiple of 8 that still covers `total` when split into eighths
+static inline int blocks_for_xcd(int64_t total, int cap_mult) {
+    int64_t per = ((total + 7) / 8 + CGNN_BLOCK - 1) / CGNN_BLOCK;     // blocks needed by the largest eighth
+    const int64_t cap = (int64_t)num_cus() * cap_mult / 8;
+    if (per > cap) per = cap;
+    if (per < 1) per = 1;
+    return (int)(per * 8);
+}
+
 }  // namespace cgnn
 
 using namespace cgnn;
@@ -517,7 +547,7 @@ int cgnn_aggregate(const float* table, int32_t table_layout, const int32_t* gath
             aggregate_fixedk_tiled_kernel<<<blocks_for(num_nodes * chunks, 64), CGNN_BLOCK, 0, st>>>(
                 table, fixed_k, num_nodes, chunks, out);
         else
-            aggregate_fixedk_kernel<<<blocks_for(num_nodes * chunks, 64), CGNN_BLOCK, 0, st>>>(
+            aggregate_fixedk_kernel<<<blocks_for_xcd(num_nodes * chunks, 64), CGNN_BLOCK, 0, st>>>(
                 table, gather, fixed_k, num_nodes, chunks, out);
         return check_hip(hipGetLastError(), "cgnn_aggregate(fixed_k) launch");
     }
