@@ -228,15 +228,21 @@ class ShardedForward:
         self.P = P
         self.x_all, self.ps, self.pd, self.agg = self._buffers(D, H, sh.x_feat.device)
         ops.mlp_rows(P["enc_node"], sh.x_feat, out=self.x_all[:sh.n_owned])
+        self._projected = False
         self.el = ops.mlp_rows(P["enc_edge"], sh.edge_attr, tiled=True)
         self.e_upd = self.el.empty_like() if m.message_source == "edge" else None
 
     def round(self, i: int):
         m, sh = self.model, self.sh
-        p = self.P["rounds"][i]
+        rounds = self.P["rounds"]
+        p = rounds[i]
         x_own = self.x_all[:sh.n_owned]
-        ops.project_nodes(p.ws, None, self.x_all, self.ps, None, p.p_format)    # senders may be ghosts
-        ops.project_nodes(None, p.wd, x_own, None, self.pd, p.p_format)         # receivers are owned
+        ps_own, ps_ghost = self.ps[:sh.n_owned], self.ps[sh.n_owned:]
+        # sender projections of the ghost rows that just arrived (receivers are always owned: no Pd for ghosts)
+        if sh.n_ghost:
+            ops.project_nodes(p.ws, None, self.x_all[sh.n_owned:], ps_ghost, None, p.p_format)
+        if not self._projected:     # first round: the owned rows too (later rounds: emitted by the node kernel)
+            ops.project_nodes(p.ws, p.wd, x_own, ps_own, self.pd, p.p_format)
         edge_mode = m.message_source == "edge"
         if edge_mode and p.edge.precision == _lib.BF16_N16 and sh.k in (8, 16):   # aggregation folded in
             ops.edge_block(p.edge, self.ps, self.pd, sh.src_local, sh.dst_local, self.el, self.el, None, True,
@@ -249,7 +255,14 @@ class ShardedForward:
             else:
                 ops.aggregate(self.x_all, sh.src_local, sh.dst_local, sh.n_owned, sh.k, sh.src_local.numel(),
                               self.agg)
-        ops.node_block(p.node, p.wx, p.wa, x_own, self.agg, x_own, True)
+        nxt = None
+        if i + 1 < len(rounds):
+            q = rounds[i + 1]
+            if q.p_format == p.p_format and q.p_dtype == self.ps.dtype:
+                fused_ok = p.node.precision == _lib.F32X3_N16 and q.ws_fused.precision == _lib.BF16_N16
+                nxt = (q.ws_fused if fused_ok else q.ws, q.wd_fused if fused_ok else q.wd, ps_own, self.pd, q.p_format)
+        ops.node_block(p.node, p.wx, p.wa, x_own, self.agg, x_own, True, nxt)
+        self._projected = nxt is not None
 
     def decode(self) -> dict:
         x_own = self.x_all[:self.sh.n_owned]
