@@ -12,8 +12,10 @@
 
 namespace cgnn {
 
-#define CGNN_NODE_N16_BLOCK 512          // (two 256-thread workgroups per CU with 24-KB chunks measured the same)
+#define CGNN_NODE_N16_BLOCK 512          // measured alternatives: two 256-thread workgroups per CU with 24-KB chunks
+                                         // (0.89-1.20 ms vs 0.84-0.88 ms), s_setprio around the MFMA groups (no change)
 #define CGNN_NODE_N16_CHUNK_FRAGS 16
+#define CGNN_NODE_N16_BPC 1
 #define CGNN_NODE_N16_CHUNK_BYTES (CGNN_NODE_N16_CHUNK_FRAGS * 3 * 1024)
 
 template <int T, int PFMT>
@@ -137,7 +139,7 @@ static int launch(const MlpDev& m, const X3Chunks& ch, const float* b1, const fl
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                        "hipFuncSetAttribute(node_block_x3n16)");
     if (rc != CGNN_OK) return rc;
-    const int grid = grid_for_tiles((n + 15) / 16, 1, CGNN_NODE_N16_BLOCK / 64);
+    const int grid = grid_for_tiles((n + 15) / 16, CGNN_NODE_N16_BPC, CGNN_NODE_N16_BLOCK / 64);
     kern<<<grid, CGNN_NODE_N16_BLOCK, lds, st>>>(m, ch, b1, x, agg, n, x_out, residual, bd, (__bf16*)ps, (__bf16*)pd);
     return check_hip(hipGetLastError(), "cgnn_node_block(x3 n16) launch");
 }
