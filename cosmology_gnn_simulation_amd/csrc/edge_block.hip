@@ -212,6 +212,83 @@ static int launch_edge_n16(const MlpDev& m, size_t lds, const __bf16* ps, const 
     return check_hip(hipGetLastError(), "cgnn_edge_block(n16) launch");
 }
 
+// Edge encoder in the N16 layout (reference graph_network.py:57: MLP + LayerNorm on the 4 edge features): narrow
+// input (<= 32 features), weights packed CGNN_BF16_N16 and resident in LDS, output written straight into the
+// TILED32 edge-latent buffer.  Same structure as the edge block: 16 edges per wave, two waves per SIMD.
+#define CGNN_EDGE_ENC_BLOCK 1024   // ~90 registers per wave: four waves per SIMD share the LDS-resident weights
+template <int HT, int DT>
+__global__ __launch_bounds__(CGNN_EDGE_ENC_BLOCK) void edge_encode_n16_kernel(MlpDev m, const float* __restrict__ x,
+                                                                             int64_t n, int ld_x, float* __restrict__ y) {
+    stage_weights_to_lds(m, 0);
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    constexpr int D = 32 * DT, DO = 2 * DT, HO = 2 * HT;
+    const int in_dim = m.in_dim[0];
+    const int64_t tiles = (n + 15) / 16;
+    const TileRange tr = tile_range(tiles);
+    for (int64_t tile = tr.first; tile < tr.end; tile += tr.stride) {
+        const int64_t e = tile * 16 + c;
+        const int64_t ec = e < n ? e : n - 1;
+        bf16x8 op[1];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int f = 16 * (j >> 2) + 4 * q + (j & 3);        // phi(0, q, j), n16.hpp
+            op[0][j] = (__bf16)(f < in_dim ? x[ec * ld_x + f] : 0.f);
+        }
+        bf16x8 oph[HT];
+        {
+            f32x4 acc[HO];
+            fill16<HO>(acc, VecSel<true>::bias(m, 0), q);
+            dense16<1, HO>(acc, op, WSel<CGNN_BF16, true>::get(m, 0), lane);
+            operand16<true, HT>(oph, acc);
+        }
+        for (int l = 1; l < m.nh; ++l) {
+            f32x4 acc[HO];
+            fill16<HO>(acc, VecSel<true>::bias(m, l), q);
+            dense16<HT, HO>(acc, oph, WSel<CGNN_BF16, true>::get(m, l), lane);
+            operand16<true, HT>(oph, acc);
+        }
+        f32x4 out[DO];
+        fill16<DO>(out, VecSel<true>::bias(m, m.nh), q);
+        dense16<HT, DO>(out, oph, WSel<CGNN_BF16, true>::get(m, m.nh), lane);
+        layer_norm16<DO>(out, VecSel<true>::gamma(m), VecSel<true>::beta(m), q);
+        const int64_t tbase = (tile >> 1) * (32 * D) + n16_lane_offset(c, q, (int)(tile & 1));
+#pragma unroll
+        for (int o = 0; o < DO; ++o) *reinterpret_cast<f32x4*>(y + tbase + n16_tile_offset(o)) = out[o];
+    }
+}
+
+template <int HT, int DT>
+static int launch_edge_encode_n16(const MlpDev& m, size_t lds, const float* x, int64_t n, int ld_x, float* y,
+                                  hipStream_t st) {
+    auto kern = edge_encode_n16_kernel<HT, DT>;
+    if (lds > 48 * 1024) {
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                           "hipFuncSetAttribute(edge_encode_n16)");
+        if (rc != CGNN_OK) return rc;
+    }
+    const int grid = grid_for_tiles((n + 15) / 16, 1, CGNN_EDGE_ENC_BLOCK / 64);
+    kern<<<grid, CGNN_EDGE_ENC_BLOCK, lds, st>>>(m, x, n, ld_x, y);
+    return check_hip(hipGetLastError(), "cgnn_mlp_rows(n16 encoder) launch");
+}
+
+// Entry used by cgnn_mlp_rows (mlp_rows.hip) for CGNN_BF16_N16 weights.
+int mlp_rows_n16_encoder(const MlpDev& m, size_t lds, const float* x, int64_t n, int ld_x, float* y, hipStream_t st) {
+    const int hidden = m.out_dim[0], latent = m.out_dim[m.nh];
+    if (m.in_dim[0] > 32 || hidden % 32 || latent % 32 || lds > CGNN_LDS_WEIGHT_BUDGET || m.gamma == nullptr) {
+        set_error("cgnn_mlp_rows: CGNN_BF16_N16 is the edge-encoder path (input <= 32 features, LayerNorm, weights "
+                  "resident in LDS)");
+        return CGNN_ERR_UNSUPPORTED;
+    }
+    const int HT = hidden / 32, DT = latent / 32;
+#define CGNN_ENC(Hh, Dd) \
+    if (HT == Hh && DT == Dd) return launch_edge_encode_n16<Hh, Dd>(m, lds, x, n, ld_x, y, st);
+    CGNN_ENC(1, 1) CGNN_ENC(2, 2) CGNN_ENC(4, 4) CGNN_ENC(4, 2)
+#undef CGNN_ENC
+    set_error("cgnn_mlp_rows: no CGNN_BF16_N16 encoder kernel for hidden=%d latent=%d", hidden, latent);
+    return CGNN_ERR_UNSUPPORTED;
+}
+
 template <int PREC, bool WLDS, int HT, int DT>
 static int launch_edge(const MlpDev& m, size_t lds, const typename PRow<PREC>::elem* ps,
                        const typename PRow<PREC>::elem* pd, const int32_t* src,

@@ -85,6 +85,9 @@ __global__ __launch_bounds__(CGNN_BLOCK) void project_kernel(const void* ws, con
     }
 }
 
+int mlp_rows_n16_encoder(const MlpDev& m, size_t lds, const float* x, int64_t n, int ld_x, float* y,
+                         hipStream_t st);   // edge_block.hip
+
 template <int PREC, bool WLDS, int K0T, int HT, int OT>
 static int launch_mlp_rows(const MlpDev& m, size_t lds, const float* x, int64_t n, int ld_x, float* y, int ld_y,
                            int y_tiled, hipStream_t st) {
@@ -126,9 +129,22 @@ int cgnn_mlp_rows(const cgnn_mlp* mlp, const float* x, int64_t n, int32_t ld_x, 
                   m.in_dim[0], ld_y, m.out_dim[m.nh]);
         return CGNN_ERR_INVALID_ARG;
     }
-    if (mlp->precision == CGNN_BF16_N16 || mlp->precision == CGNN_F32X3_N16) {
-        set_error("cgnn_mlp_rows: N16-packed weights are for cgnn_edge_block / cgnn_node_block only");
+    if (mlp->precision == CGNN_F32X3_N16) {
+        set_error("cgnn_mlp_rows: CGNN_F32X3_N16 weights are for cgnn_node_block only");
         return CGNN_ERR_UNSUPPORTED;
+    }
+    if (mlp->precision == CGNN_BF16_N16) {   // the edge encoder: narrow input -> TILED32 latents, 16 edges per wave
+        if (y_layout != CGNN_TILED32) {
+            set_error("cgnn_mlp_rows: CGNN_BF16_N16 weights write CGNN_TILED32 output only");
+            return CGNN_ERR_UNSUPPORTED;
+        }
+        if (n == 0) return CGNN_OK;
+        for (int l = 1; l < m.nh; ++l)
+            if (m.in_dim[l] != m.out_dim[0] || m.out_dim[l] != m.out_dim[0]) {
+                set_error("cgnn_mlp_rows: hidden layer %d has the wrong shape", l);
+                return CGNN_ERR_INVALID_ARG;
+            }
+        return mlp_rows_n16_encoder(m, lds, x, n, ld_x, y, (hipStream_t)stream);
     }
     if (n == 0) return CGNN_OK;
     const int hidden = m.out_dim[0];

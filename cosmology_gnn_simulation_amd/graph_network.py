@@ -387,9 +387,13 @@ class EncodeProcessDecode(nn.Module):
         if self._packed is not None and self._packed[0] == key:
             return self._packed[1]
         D = self._latent_size
+        enc_edge = _pack_mlp(self.encoder.edge_model, self.edge_precision)
+        if enc_edge.precision == _lib.BF16 and enc_edge.in_dim <= 32 and D <= 128 and enc_edge.hidden <= 128 and \
+                enc_edge.lds_bytes() <= _lib.LDS_WEIGHT_BUDGET:
+            enc_edge = _pack_mlp(self.encoder.edge_model, "bf16_n16")    # 16-edge-per-wave encoder, TILED32 output
         packed = dict(
             enc_node=_pack_mlp(self.encoder.node_model, self.node_precision),
-            enc_edge=_pack_mlp(self.encoder.edge_model, self.edge_precision),
+            enc_edge=enc_edge,
             rounds=[_PackedProcessor(net, D, self.edge_precision, self.node_precision) for net in self.processor],
             dec_acc=_pack_mlp(self.decoder_acc, self.node_precision),
             dec_tr=_pack_mlp(self.decoder_temp_rate, self.node_precision),

@@ -44,7 +44,9 @@ typedef enum {
     CGNN_F32 = 0,      /* f32 operands, v_mfma_f32_32x32x2_f32, exact f32 (parity mode)     */
     CGNN_BF16 = 1,     /* bf16 operands, v_mfma_f32_32x32x16_bf16, f32 accumulate           */
     CGNN_BF16_N16 = 2, /* same arithmetic as CGNN_BF16, weights packed for the 16-edge-per-
-                          wave kernel (v_mfma_f32_16x16x32_bf16); cgnn_edge_block only      */
+                          wave kernels (v_mfma_f32_16x16x32_bf16): cgnn_edge_block, and
+                          cgnn_mlp_rows as the edge encoder (input <= 32 features, LayerNorm,
+                          CGNN_TILED32 output)                                             */
     CGNN_F32X3 = 3,    /* f32 emulated on the bf16 matrix cores: operands split into three bf16
                           terms (8+8+8 significand bits), the six products whose weight is
                           >= 2^-16 accumulated in f32 (a1b1,a1b2,a2b1,a2b2,a1b3,a3b1); dropped
