@@ -84,10 +84,9 @@ def load() -> C.CDLL:
     lib.cgnn_window_features.argtypes = [vp, vp, vp, vp, i32, i64, f32, f32, f32, f32, f32, f32, vp, vp, vp]
     lib.cgnn_gather_rows.argtypes = [vp, vp, i64, i32, vp, vp]
     lib.cgnn_scatter_rows.argtypes = [vp, vp, i64, i32, vp, vp]
-    for name in EXPORTS:
-        fn = getattr(lib, name)
-        if fn.restype is C.c_int and name not in ("cgnn_version",):
-            fn.restype = C.c_int
+    missing = [name for name in EXPORTS if not hasattr(lib, name)]
+    if missing:
+        raise CgnnError(f"{LIB_PATH} lacks {missing}: rebuild it (make -C cosmology_gnn_simulation_amd/csrc)")
     _lib = lib
     return lib
 

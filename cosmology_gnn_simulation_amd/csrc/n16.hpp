@@ -168,13 +168,6 @@ __device__ __forceinline__ constexpr int n16_tile_offset(int O) { return (4 * (O
 // CGNN_F32X3 arithmetic in the N16 layout (node kernel): three bf16 terms per value, six MFMAs per fragment.
 namespace cgnn {
 
-struct Operand16x3 {   // KS k-steps, three terms each
-    template <int KS>
-    struct T {
-        bf16x8 v[3][KS];
-    };
-};
-
 template <bool RELU, int KS>
 __device__ __forceinline__ void operand16x3(bf16x8 (&op)[3][KS], const f32x4 (&acc)[2 * KS]) {
 #pragma unroll

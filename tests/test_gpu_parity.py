@@ -115,6 +115,21 @@ def test_knn_periodic_bit_exact(n, k, box, seed):
     assert sorted(order.cpu().tolist()) == list(range(n))          # the locality order is a permutation
 
 
+def test_knn_clustered_positions_bit_exact():
+    """Strongly non-uniform input (tight clumps on a sparse background, the regime of real cosmological
+    snapshots): crowded and empty cells, neighbours many shells away, clumps straddling the periodic boundary."""
+    gen = torch.Generator().manual_seed(17)
+    centers = torch.rand(12, 3, generator=gen)
+    centers[0] = torch.tensor([0.999, 0.001, 0.5])                  # a clump on the box corner/edge
+    clumps = (centers.repeat_interleave(250, 0) + 0.004 * torch.randn(3000, 3, generator=gen)) % 1.0
+    pos = torch.cat([clumps, torch.rand(500, 3, generator=gen)]).float()
+    for k in (8, 16):
+        ei, ea = cpu_ref.knn_periodic(pos, 1.0, k)
+        snd, attr, _ = ops.knn_periodic(pos.to(DEV), 1.0, k)
+        assert torch.equal(snd.cpu().long(), ei[0])
+        assert torch.equal(attr.cpu()[:, :3], ea[:, :3])
+
+
 def test_knn_query_subset_and_duplicates():
     gen = torch.Generator().manual_seed(9)
     pos = torch.rand(500, 3, generator=gen)
