@@ -226,9 +226,9 @@ def main():
         calls, total_ms = per_op["edge_block"]
         edge_ms = total_ms / calls
         sz_w = 2 if args.edge_precision == "bf16" else 4
-        # algorithmic HBM bytes per launch: edge latents read once + written once, src/dst indices, and the
-        # per-node Ps/Pd tables read once (gather re-reads are cache traffic, not algorithmic bytes)
-        alg_bytes = 2 * e_local * d * 4 + 2 * e_local * 4 + 2 * n_local * h * 4
+        # algorithmic HBM bytes per launch: f32 edge latents read once + written once, src/dst indices, and the
+        # per-node Ps/Pd tables (bf16 in bf16 mode) read once (gather re-reads are cache traffic, not algorithmic)
+        alg_bytes = 2 * e_local * d * 4 + 2 * e_local * 4 + 2 * n_local * h * (2 if args.edge_precision == "bf16" else 4)
         achieved = alg_bytes / (edge_ms * 1e-3) / 1e9
         flops_exec = 2.0 * e_local * (d * h + (args.hidden_layers - 1) * h * h + h * d)
         flops_alg = 2.0 * e_local * (3 * d * h + (args.hidden_layers - 1) * h * h + h * d)

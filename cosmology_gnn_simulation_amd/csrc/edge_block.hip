@@ -122,10 +122,14 @@ static int launch_edge_lds(const MlpDev& m, size_t lds, const __bf16* ps, const 
     return check_hip(hipGetLastError(), "cgnn_edge_block(lds) launch");
 }
 
+#ifndef CGNN_EDGE_N16_BLOCK
+#define CGNN_EDGE_N16_BLOCK 512
+#define CGNN_EDGE_N16_GS 4
+#endif
 // N16 variant (weights packed CGNN_BF16_N16, P tables CGNN_P_BF16_S16): 16 edges per wave, see n16.hpp.  The
 // f32 tile is read once, kept in registers for the residual, and written once.
 template <int HT, int DT>
-__global__ __launch_bounds__(CGNN_EDGE_LDS_BLOCK) void edge_block_n16_kernel(
+__global__ __launch_bounds__(CGNN_EDGE_N16_BLOCK) void edge_block_n16_kernel(
     MlpDev m, const __bf16* __restrict__ ps, const __bf16* __restrict__ pd, const int32_t* __restrict__ src,
     const int32_t* __restrict__ dst, int64_t num_edges, const float* e_in, float* e_out, float* e_upd, int residual,
     const float* __restrict__ x_gather, float* __restrict__ agg_out, int seg_k) {
@@ -141,7 +145,8 @@ __global__ __launch_bounds__(CGNN_EDGE_LDS_BLOCK) void edge_block_n16_kernel(
         const int64_t tbase = (tile >> 1) * (32 * D) + n16_lane_offset(c, q, (int)(tile & 1));
         f32x4 ev[DO];
 #pragma unroll
-        for (int o = 0; o < DO; ++o) ev[o] = *reinterpret_cast<const f32x4*>(e_in + tbase + n16_tile_offset(o));
+        for (int o = 0; o < DO; ++o)   // streamed once: non-temporal, so that the P-table rows keep their L2 lines
+            ev[o] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(e_in + tbase + n16_tile_offset(o)));
         bf16x8 oph[HT];
         {
             bf16x8 op[DT];
@@ -149,18 +154,18 @@ __global__ __launch_bounds__(CGNN_EDGE_LDS_BLOCK) void edge_block_n16_kernel(
             f32x4 acc[HO];
             load_p16<HO, false>(acc, ps, s, q);
             load_p16<HO, true>(acc, pd, d, q);
-            dense16<DT, HO>(acc, op, WSel<CGNN_BF16, true>::get(m, 0), lane);
+            dense16<DT, HO, CGNN_EDGE_N16_GS>(acc, op, WSel<CGNN_BF16, true>::get(m, 0), lane);
             operand16<true, HT>(oph, acc);
         }
         for (int l = 1; l < m.nh; ++l) {
             f32x4 acc[HO];
             fill16<HO>(acc, VecSel<true>::bias(m, l), q);
-            dense16<HT, HO>(acc, oph, WSel<CGNN_BF16, true>::get(m, l), lane);
+            dense16<HT, HO, CGNN_EDGE_N16_GS>(acc, oph, WSel<CGNN_BF16, true>::get(m, l), lane);
             operand16<true, HT>(oph, acc);
         }
         f32x4 out[DO];
         fill16<DO>(out, VecSel<true>::bias(m, m.nh), q);
-        dense16<HT, DO>(out, oph, WSel<CGNN_BF16, true>::get(m, m.nh), lane);
+        dense16<HT, DO, CGNN_EDGE_N16_GS>(out, oph, WSel<CGNN_BF16, true>::get(m, m.nh), lane);
         layer_norm16<DO>(out, VecSel<true>::gamma(m), VecSel<true>::beta(m), q);
         if (e_upd != nullptr) {
 #pragma unroll
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(CGNN_EDGE_LDS_BLOCK) void edge_block_n16_kernel(
 #pragma unroll
         for (int o = 0; o < DO; ++o) {
             if (residual) out[o] += ev[o];
-            *reinterpret_cast<f32x4*>(e_out + tbase + n16_tile_offset(o)) = out[o];
+            __builtin_nontemporal_store(out[o], reinterpret_cast<f32x4*>(e_out + tbase + n16_tile_offset(o)));
         }
         if (agg_out != nullptr && x_gather != nullptr) {   // PyG default message: aggregate the sender node rows
             const bool writer = (c & (seg_k - 1)) == 0 && e < num_edges;
@@ -206,8 +211,8 @@ static int launch_edge_n16(const MlpDev& m, size_t lds, const __bf16* ps, const 
                            "hipFuncSetAttribute(edge_block_n16)");
         if (rc != CGNN_OK) return rc;
     }
-    const int grid = grid_for_tiles((num_edges + 15) / 16, 1, CGNN_EDGE_LDS_BLOCK / 64);
-    kern<<<grid, CGNN_EDGE_LDS_BLOCK, lds, st>>>(m, ps, pd, src, dst, num_edges, e_in, e_out, e_upd, residual, x_gather,
+    const int grid = grid_for_tiles((num_edges + 15) / 16, 1, CGNN_EDGE_N16_BLOCK / 64);
+    kern<<<grid, CGNN_EDGE_N16_BLOCK, lds, st>>>(m, ps, pd, src, dst, num_edges, e_in, e_out, e_upd, residual, x_gather,
                                                  agg_out, seg_k);
     return check_hip(hipGetLastError(), "cgnn_edge_block(n16) launch");
 }

@@ -20,10 +20,10 @@ namespace cgnn {
 typedef const __attribute__((address_space(3))) f32x4* LdsVec4Ptr;
 
 // out[O] += W[16 O .. 16 O + 15, :] . in    fragment m = O * KS + s at wp[m * 64 + lane]
-template <int KS, int OT>
+template <int KS, int OT, int GSMAX = 4>
 __device__ __forceinline__ void dense16(f32x4 (&out)[OT], const bf16x8 (&in)[KS], const LdsW& wp, int lane) {
     constexpr int M = OT * KS;
-    constexpr int GS = (M < 4) ? M : 4;
+    constexpr int GS = (M < GSMAX) ? M : GSMAX;
     constexpr int NG = M / GS;
     static_assert(M % GS == 0, "group size must divide the MFMA count");
     bf16x8 buf[2][GS];
