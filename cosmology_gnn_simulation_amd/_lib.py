@@ -28,6 +28,7 @@ EXPORTS = (
     "cgnn_mlp_rows", "cgnn_project_nodes", "cgnn_edge_block", "cgnn_aggregate", "cgnn_node_block",
     "cgnn_knn_workspace_bytes", "cgnn_knn_periodic", "cgnn_knn_sorted_order", "cgnn_segment_colsum",
     "cgnn_gather_rows", "cgnn_scatter_rows", "cgnn_tiled_rows", "cgnn_relayout", "cgnn_window_features",
+    "cgnn_mlp_backward", "cgnn_weight_grad", "cgnn_col_dot",
 )
 ROWS, TILED32 = 0, 1
 
@@ -40,6 +41,11 @@ class Mlp(C.Structure):
     _fields_ = [("precision", C.c_int32), ("num_hidden_layers", C.c_int32),
                 ("layer", Linear * (MAX_HIDDEN_LAYERS + 1)),
                 ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p)]
+
+
+class MlpBwdBuffers(C.Structure):
+    _fields_ = [("h", C.c_void_p * MAX_HIDDEN_LAYERS), ("g_a", C.c_void_p * MAX_HIDDEN_LAYERS),
+                ("g_o", C.c_void_p), ("zhat", C.c_void_p)]
 
 
 class CgnnError(RuntimeError):
@@ -84,6 +90,10 @@ def load() -> C.CDLL:
     lib.cgnn_window_features.argtypes = [vp, vp, vp, vp, i32, i64, f32, f32, f32, f32, f32, f32, vp, vp, vp]
     lib.cgnn_gather_rows.argtypes = [vp, vp, i64, i32, vp, vp]
     lib.cgnn_scatter_rows.argtypes = [vp, vp, i64, i32, vp, vp]
+    lib.cgnn_mlp_backward.argtypes = [C.POINTER(Mlp), C.POINTER(Linear), C.POINTER(Mlp), C.POINTER(Linear), vp, i32, vp,
+                                      i32, vp, i32, i64, C.POINTER(MlpBwdBuffers), vp, i32, vp, i32, vp]
+    lib.cgnn_weight_grad.argtypes = [vp, i32, i32, vp, i32, i32, i64, vp, i32, i32, vp]
+    lib.cgnn_col_dot.argtypes = [vp, i32, vp, i32, i64, i32, vp, vp]
     missing = [name for name in EXPORTS if not hasattr(lib, name)]
     if missing:
         raise CgnnError(f"{LIB_PATH} lacks {missing}: rebuild it (make -C cosmology_gnn_simulation_amd/csrc)")

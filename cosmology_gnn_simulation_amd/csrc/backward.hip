@@ -1,0 +1,359 @@
+// Backward of the node stream (reference train.py:263 `combined_loss.backward()` through
+// graph_network.py:94-96,154-183): cgnn_mlp_backward, cgnn_weight_grad, cgnn_col_dot.  Exact f32 MFMA.
+//
+// In reference-faithful mode (PyG's default message) only the node encoder, the node models and the decoders
+// receive gradient, all of them row-wise MLPs (+LayerNorm); the aggregation's transpose is
+// cgnn_aggregate with src/dst swapped.  The data-gradient kernel below recomputes the forward of its 32-row tile
+// instead of reading saved activations, and leaves the per-layer activations and pre-activation gradients in
+// scratch matrices from which the weight gradients are plain row reductions.
+#include <string.h>
+
+#include "mlp_device.hpp"
+
+namespace cgnn {
+
+struct BwdBufs {
+    float* h[CGNN_MAX_HIDDEN_LAYERS];
+    float* g_a[CGNN_MAX_HIDDEN_LAYERS];
+    float* g_o;
+    float* zhat;
+};
+
+template <int T>
+__device__ __forceinline__ void zero_tiles(f32x16 (&a)[T]) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[t][i] = 0.f;
+}
+
+// K1T / K2T: 32-feature tiles of the two input parts (K2T = 0: single input); HT hidden tiles; OT output tiles.
+template <int K1T, int K2T, int HT, int OT, bool LN>
+__global__ __launch_bounds__(CGNN_BLOCK) void mlp_backward_kernel(
+    MlpDev f, MlpDev b, const void* f_w2, const void* b_w2, const float* __restrict__ u1, int ld1,
+    const float* __restrict__ u2, int ld2, const float* __restrict__ dy, int ld_dy, int64_t n, BwdBufs buf,
+    float* __restrict__ du1, int ld_du1, float* __restrict__ du2, int ld_du2) {
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int64_t tiles = (n + 31) / 32;
+    constexpr int H = 32 * HT, OW = 32 * OT;
+    constexpr int K2 = K2T > 0 ? K2T : 1;
+    const int in1 = f.in_dim[0], out_dim = f.out_dim[f.nh];
+    const bool in1_full = (in1 == 32 * K1T) && (ld1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(u1) & 15) == 0);
+    const BufW<CGNN_F32> fw2(f_w2, K2 * HT * 4096u), bw2(b_w2, K2 * HT * 4096u);
+    const TileRange tr = tile_range(tiles);
+    for (int64_t tile = tr.first; tile < tr.end; tile += tr.stride) {
+        const int64_t row = tile * 32 + r;
+        const bool live = row < n;
+        const int64_t rowc = live ? row : n - 1;
+        // ------------------------------------------------------------ forward, recomputed
+        Operand<CGNN_F32, HT> oph;
+        {
+            f32x16 acc[HT];
+            acc_fill_bias<HT>(acc, f.b[0], H, h);
+            {
+                Operand<CGNN_F32, K1T> op;
+                if (in1_full)
+                    load_rows_full<K1T>(op.v, u1 + rowc * ld1, h);
+                else
+                    load_rows_ragged<K1T>(op.v, u1 + rowc * ld1, in1, h);
+                dense<K1T, HT>(acc, op, WSel<CGNN_F32, false>::get(f, 0), lane);
+            }
+            if (K2T > 0) {
+                Operand<CGNN_F32, K2> op;
+                load_rows_full<K2>(op.v, u2 + rowc * ld2, h);
+                dense<K2, HT>(acc, op, fw2, lane);
+            }
+            oph.template from_acc<true>(acc);
+            if (live) store_rows_full<HT>(oph.v, buf.h[0] + row * H, h);
+        }
+        for (int l = 1; l < f.nh; ++l) {
+            f32x16 acc[HT];
+            acc_fill_bias<HT>(acc, f.b[l], H, h);
+            dense<HT, HT>(acc, oph, WSel<CGNN_F32, false>::get(f, l), lane);
+            oph.template from_acc<true>(acc);
+            if (live) store_rows_full<HT>(oph.v, buf.h[l] + row * H, h);
+        }
+        f32x16 g[OT];      // becomes dL/d(pre-LayerNorm output)
+        {
+            f32x16 out[OT];
+            acc_fill_bias<OT>(out, f.b[f.nh], out_dim, h);
+            dense<HT, OT>(out, oph, WSel<CGNN_F32, false>::get(f, f.nh), lane);
+            // -------------------------------------------------------- output gradient through LayerNorm
+            if (out_dim == OW && ld_dy % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0)
+                load_rows_full<OT>(g, dy + rowc * ld_dy, h);
+            else
+                load_rows_ragged<OT>(g, dy + rowc * ld_dy, out_dim, h);
+            if (LN) {
+                float s = 0.f;
+#pragma unroll
+                for (int t = 0; t < OT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) s += out[t][i];
+                s += __shfl_xor(s, 32);
+                const float mean = s * (1.0f / OW);
+                float q = 0.f;
+#pragma unroll
+                for (int t = 0; t < OT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float d = out[t][i] - mean;
+                        q += d * d;
+                    }
+                q += __shfl_xor(q, 32);
+                const float rstd = 1.0f / sqrtf(q * (1.0f / OW) + 1e-5f);
+                float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+                for (int t = 0; t < OT; ++t)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const f32x4 gm = *reinterpret_cast<const f32x4*>(f.gamma + 32 * t + 8 * gq + 4 * h);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int i = 4 * gq + c;
+                            const float z = (out[t][i] - mean) * rstd;
+                            out[t][i] = z;                       // out now holds zhat
+                            const float gz = g[t][i] * gm[c];
+                            g[t][i] = gz;                        // g now holds dL/dzhat
+                            m1 += gz;
+                            m2 += gz * z;
+                        }
+                    }
+                m1 += __shfl_xor(m1, 32);
+                m2 += __shfl_xor(m2, 32);
+                m1 *= (1.0f / OW);
+                m2 *= (1.0f / OW);
+                if (live) store_rows_full<OT>(out, buf.zhat + row * OW, h);
+#pragma unroll
+                for (int t = 0; t < OT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) g[t][i] = rstd * (g[t][i] - m1 - out[t][i] * m2);
+            }
+        }
+        if (live) store_rows_full<OT>(g, buf.g_o + row * OW, h);
+        // ------------------------------------------------------------ backward through the hidden layers
+        Operand<CGNN_F32, HT> og;     // dL/d(pre-activation) of the layer being left
+        {
+            Operand<CGNN_F32, OT> go;
+            go.template from_acc<false>(g);
+            f32x16 gh[HT];
+            zero_tiles<HT>(gh);
+            dense<OT, HT>(gh, go, WSel<CGNN_F32, false>::get(b, f.nh), lane);     // W_nh^T
+            f32x16 hv[HT];
+            load_rows_full<HT>(hv, buf.h[f.nh - 1] + rowc * H, h);
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) og.v[t][i] = hv[t][i] > 0.f ? gh[t][i] : 0.f;
+            if (live) store_rows_full<HT>(og.v, buf.g_a[f.nh - 1] + row * H, h);
+        }
+        for (int l = f.nh - 1; l >= 1; --l) {
+            f32x16 gh[HT];
+            zero_tiles<HT>(gh);
+            dense<HT, HT>(gh, og, WSel<CGNN_F32, false>::get(b, l), lane);        // W_l^T
+            f32x16 hv[HT];
+            load_rows_full<HT>(hv, buf.h[l - 1] + rowc * H, h);
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) og.v[t][i] = hv[t][i] > 0.f ? gh[t][i] : 0.f;
+            if (live) store_rows_full<HT>(og.v, buf.g_a[l - 1] + row * H, h);
+        }
+        // ------------------------------------------------------------ input gradients
+        if (du1 != nullptr) {
+            f32x16 gx[K1T];
+            zero_tiles<K1T>(gx);
+            dense<HT, K1T>(gx, og, WSel<CGNN_F32, false>::get(b, 0), lane);       // W_0a^T
+            if (live) {
+                if (in1_full && ld_du1 % 4 == 0)
+                    store_rows_full<K1T>(gx, du1 + row * ld_du1, h);
+                else
+                    store_rows_ragged<K1T>(gx, du1 + row * ld_du1, in1, h);
+            }
+        }
+        if (K2T > 0 && du2 != nullptr) {
+            f32x16 gx[K2];
+            zero_tiles<K2>(gx);
+            dense<HT, K2>(gx, og, bw2, lane);                                     // W_0b^T
+            if (live) store_rows_full<K2>(gx, du2 + row * ld_du2, h);
+        }
+    }
+}
+
+// dw[o, col0+i] += sum_r g[r,o] a[r,i]: one 32x32 output tile per wave over a chunk of rows.
+#define CGNN_WGRAD_ROWS 4096
+__global__ __launch_bounds__(CGNN_BLOCK) void weight_grad_kernel(const float* __restrict__ g, int ld_g, int out_dim,
+                                                                 const float* __restrict__ a, int ld_a, int in_dim,
+                                                                 int64_t n, int it_tiles, int n_tiles,
+                                                                 float* __restrict__ dw, int ld_dw, int col0) {
+    const int lane = threadIdx.x & 63, i = lane & 31, kk = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = blockIdx.y * CGNN_WAVES_PER_BLOCK + wave;
+    if (t >= n_tiles) return;
+    const int ot = t / it_tiles, it = t % it_tiles;
+    const int64_t r0 = (int64_t)blockIdx.x * CGNN_WGRAD_ROWS;
+    const int64_t r1 = r0 + CGNN_WGRAD_ROWS < n ? r0 + CGNN_WGRAD_ROWS : n;
+    const int oc = 32 * ot + i, ic = 32 * it + i;
+    const bool o_ok = oc < out_dim, i_ok = ic < in_dim;
+    f32x16 acc;
+#pragma unroll
+    for (int x = 0; x < 16; ++x) acc[x] = 0.f;
+    for (int64_t rr = r0; rr < r1; rr += 16) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int64_t row = rr + 2 * s + kk;
+            const bool ok = row < r1;
+            av[s] = (ok && o_ok) ? g[row * ld_g + oc] : 0.f;
+            bv[s] = (ok && i_ok) ? a[row * ld_a + ic] : 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+    }
+    // D[row i'][col j]: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+        const int o = 32 * ot + (x & 3) + 8 * (x >> 2) + 4 * kk;
+        if (o < out_dim && i_ok) atomicAdd(dw + (int64_t)o * ld_dw + col0 + ic, acc[x]);
+    }
+}
+
+#define CGNN_COLDOT_ROWS 2048
+__global__ void col_dot_kernel(const float* __restrict__ a, int ld_a, const float* __restrict__ b, int ld_b, int64_t n,
+                               int width, float* __restrict__ out) {
+    const int64_t r0 = (int64_t)blockIdx.x * CGNN_COLDOT_ROWS;
+    const int64_t r1 = r0 + CGNN_COLDOT_ROWS < n ? r0 + CGNN_COLDOT_ROWS : n;
+    for (int c = threadIdx.x; c < width; c += blockDim.x) {
+        float s = 0.f;
+        if (b != nullptr)
+            for (int64_t r = r0; r < r1; ++r) s += a[r * ld_a + c] * b[r * ld_b + c];
+        else
+            for (int64_t r = r0; r < r1; ++r) s += a[r * ld_a + c];
+        atomicAdd(out + c, s);
+    }
+}
+
+template <int K1T, int K2T, int HT, int OT>
+static int launch_bwd(bool ln, const MlpDev& f, const MlpDev& b, const void* fw2, const void* bw2, const float* u1, int ld1,
+                      const float* u2, int ld2, const float* dy, int ld_dy, int64_t n, const BwdBufs& buf, float* du1,
+                      int ld_du1, float* du2, int ld_du2, hipStream_t st) {
+    const int grid = grid_for_tiles((n + 31) / 32);
+    if (ln)
+        mlp_backward_kernel<K1T, K2T, HT, OT, true><<<grid, CGNN_BLOCK, 0, st>>>(f, b, fw2, bw2, u1, ld1, u2, ld2, dy, ld_dy,
+                                                                               n, buf, du1, ld_du1, du2, ld_du2);
+    else
+        mlp_backward_kernel<K1T, K2T, HT, OT, false><<<grid, CGNN_BLOCK, 0, st>>>(f, b, fw2, bw2, u1, ld1, u2, ld2, dy,
+                                                                                ld_dy, n, buf, du1, ld_du1, du2, ld_du2);
+    return check_hip(hipGetLastError(), "cgnn_mlp_backward launch");
+}
+
+}  // namespace cgnn
+
+using namespace cgnn;
+
+extern "C" {
+
+int cgnn_mlp_backward(const cgnn_mlp* fwd, const cgnn_linear* fwd_part2, const cgnn_mlp* bwd,
+                      const cgnn_linear* bwd_part2, const float* u1, int32_t ld1, const float* u2, int32_t ld2,
+                      const float* dy, int32_t ld_dy, int64_t n, const cgnn_mlp_bwd_buffers* buf, float* du1,
+                      int32_t ld_du1, float* du2, int32_t ld_du2, void* stream) {
+    MlpDev f, b;
+    int rc = make_mlp_dev(fwd, &f, nullptr, "cgnn_mlp_backward(fwd)");
+    if (rc != CGNN_OK) return rc;
+    rc = make_mlp_dev(bwd, &b, nullptr, "cgnn_mlp_backward(bwd)");
+    if (rc != CGNN_OK) return rc;
+    if (fwd->precision != CGNN_F32 || bwd->precision != CGNN_F32) {
+        set_error("cgnn_mlp_backward: exact f32 (CGNN_F32) weights only");
+        return CGNN_ERR_UNSUPPORTED;
+    }
+    if (!u1 || !dy || !buf || n < 0 || f.nh != b.nh || !buf->g_o || (fwd_part2 != nullptr) != (bwd_part2 != nullptr) ||
+        (fwd_part2 && !u2)) {
+        set_error("cgnn_mlp_backward: invalid argument");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    const int hidden = f.out_dim[0], out_dim = f.out_dim[f.nh], in1 = f.in_dim[0];
+    for (int l = 0; l <= f.nh; ++l) {
+        const int want_in = l == 0 ? in1 : hidden, want_out = l == f.nh ? out_dim : hidden;
+        if (f.in_dim[l] != want_in || f.out_dim[l] != want_out || b.in_dim[l] != want_out || b.out_dim[l] != want_in) {
+            set_error("cgnn_mlp_backward: layer %d shapes are inconsistent (bwd must hold the transposed weights)", l);
+            return CGNN_ERR_INVALID_ARG;
+        }
+        if (l < f.nh && (!buf->h[l] || !buf->g_a[l])) {
+            set_error("cgnn_mlp_backward: scratch buffers for hidden layer %d are missing", l);
+            return CGNN_ERR_INVALID_ARG;
+        }
+    }
+    const bool ln = f.gamma != nullptr;
+    if (ln && !buf->zhat) {
+        set_error("cgnn_mlp_backward: zhat scratch is required with LayerNorm");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    int in2 = 0;
+    if (fwd_part2) {
+        in2 = fwd_part2->in_dim;
+        if (fwd_part2->out_dim != hidden || bwd_part2->in_dim != hidden || bwd_part2->out_dim != in2 || in2 % 32 ||
+            ld2 < in2 || (du2 && ld_du2 < in2)) {
+            set_error("cgnn_mlp_backward: second input part has inconsistent shapes");
+            return CGNN_ERR_INVALID_ARG;
+        }
+    }
+    if (hidden % 32 || (ln && out_dim % 32) || ld1 < in1 || ld_dy < out_dim || (du1 && ld_du1 < in1)) {
+        set_error("cgnn_mlp_backward: unsupported shape (hidden %d, out %d)", hidden, out_dim);
+        return CGNN_ERR_UNSUPPORTED;
+    }
+    if (n == 0) return CGNN_OK;
+    BwdBufs bb;
+    memset(&bb, 0, sizeof(bb));
+    for (int l = 0; l < f.nh; ++l) {
+        bb.h[l] = buf->h[l];
+        bb.g_a[l] = buf->g_a[l];
+    }
+    bb.g_o = buf->g_o;
+    bb.zhat = buf->zhat;
+    hipStream_t st = (hipStream_t)stream;
+    const int K1T = (in1 + 31) / 32, K2T = in2 / 32, HT = hidden / 32, OT = (out_dim + 31) / 32;
+    const void* fw2 = fwd_part2 ? fwd_part2->w : nullptr;
+    const void* bw2 = bwd_part2 ? bwd_part2->w : nullptr;
+#define CGNN_BWD(K1, K2, Hh, Oo)                                                                                  \
+    if (K1T == K1 && K2T == K2 && HT == Hh && OT == Oo)                                                            \
+        return launch_bwd<K1, K2, Hh, Oo>(ln, f, b, fw2, bw2, u1, ld1, u2, ld2, dy, ld_dy, n, bb, du1, ld_du1, du2, \
+                                          ld_du2, st);
+    // square models hidden == latent in {32, 64, 128}: node block (two inputs), encoder (narrow input), decoder
+#define CGNN_BWD_T(Tt) CGNN_BWD(Tt, Tt, Tt, Tt) CGNN_BWD(1, 0, Tt, Tt) CGNN_BWD(Tt, 0, Tt, 1)
+    CGNN_BWD_T(1) CGNN_BWD_T(2) CGNN_BWD_T(4)
+#undef CGNN_BWD_T
+#undef CGNN_BWD
+    set_error("cgnn_mlp_backward: no kernel for in=(%d,%d) hidden=%d out=%d (training is built for hidden == latent in "
+              "{32,64,128})", in1, in2, hidden, out_dim);
+    return CGNN_ERR_UNSUPPORTED;
+}
+
+int cgnn_weight_grad(const float* g, int32_t ld_g, int32_t out_dim, const float* a, int32_t ld_a, int32_t in_dim,
+                     int64_t n, float* dw, int32_t ld_dw, int32_t col0, void* stream) {
+    if (!g || !a || !dw || out_dim <= 0 || in_dim <= 0 || n < 0 || ld_g < out_dim || ld_a < in_dim ||
+        ld_dw < col0 + in_dim || col0 < 0) {
+        set_error("cgnn_weight_grad: invalid argument");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if (n == 0) return CGNN_OK;
+    const int ot = (out_dim + 31) / 32, it = (in_dim + 31) / 32;
+    const int n_tiles = ot * it;
+    dim3 grid((unsigned)((n + CGNN_WGRAD_ROWS - 1) / CGNN_WGRAD_ROWS),
+              (unsigned)((n_tiles + CGNN_WAVES_PER_BLOCK - 1) / CGNN_WAVES_PER_BLOCK));
+    weight_grad_kernel<<<grid, CGNN_BLOCK, 0, (hipStream_t)stream>>>(g, ld_g, out_dim, a, ld_a, in_dim, n, it, n_tiles,
+                                                                    dw, ld_dw, col0);
+    return check_hip(hipGetLastError(), "cgnn_weight_grad launch");
+}
+
+int cgnn_col_dot(const float* a, int32_t ld_a, const float* b, int32_t ld_b, int64_t n, int32_t width, float* out,
+                 void* stream) {
+    if (!a || !out || width <= 0 || n < 0 || ld_a < width || (b && ld_b < width)) {
+        set_error("cgnn_col_dot: invalid argument");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if (n == 0) return CGNN_OK;
+    col_dot_kernel<<<(unsigned)((n + CGNN_COLDOT_ROWS - 1) / CGNN_COLDOT_ROWS), CGNN_BLOCK, 0, (hipStream_t)stream>>>(
+        a, ld_a, b, ld_b, n, width, out);
+    return check_hip(hipGetLastError(), "cgnn_col_dot launch");
+}
+
+}  // extern "C"

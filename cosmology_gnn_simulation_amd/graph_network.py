@@ -86,8 +86,8 @@ def _needs_grad(module: nn.Module) -> bool:
     return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
 
 
-_TRAINING_MSG = ("the fused HIP forward has no backward kernels yet (SURVEY.md section 8f-1): call it under "
-                 "torch.no_grad() / model.requires_grad_(False)")
+_TRAINING_MSG = ("only EncodeProcessDecode (message_source='x_j') has backward kernels; call this module under "
+                 "torch.no_grad() / requires_grad_(False), or train through EncodeProcessDecode")
 
 
 def _params_key(module: nn.Module, *extra) -> tuple:
@@ -366,6 +366,7 @@ class EncodeProcessDecode(nn.Module):
         self.edge_precision = "fp32"
         self.locality_sort = True     # run in the k-NN build's spatial order when the graph carries it
         self._packed = None
+        self._train_packed = None
 
     # -- packing ---------------------------------------------------------------
     def _materialize_all(self, node_in: int, edge_in: int) -> None:
@@ -410,9 +411,49 @@ class EncodeProcessDecode(nn.Module):
         """Same as :meth:`forward` plus ``x_latent`` / ``edge_latent`` after the last round."""
         return self._forward(input_graph, want_latents=True)
 
+    def _train_packs(self):
+        from .training import TrainPacks
+        key = _params_key(self, "train")
+        if self._train_packed is None or self._train_packed[0] != key:
+            self._train_packed = (key, TrainPacks(self))
+        return self._train_packed[1]
+
+    def _forward_train(self, g) -> dict:
+        """Differentiable forward (exact f32) for ``train.py``: see :mod:`.training`.  Edge-model parameters get no
+        gradient, exactly as under the reference."""
+        from . import training
+        if self.message_source != "x_j":
+            raise NotImplementedError("training is built for the reference-faithful message_source='x_j'; the "
+                                      "'edge' extension has no backward kernels")
+        x = g.x
+        require_device(x, "input_graph.x")
+        edge_attr = getattr(g, "edge_attr", None)
+        if edge_attr is None:
+            raise ValueError("edge_attr must not be None in InteractionNetwork")
+        glob = getattr(g, "globals", None)
+        if glob is not None:
+            x = torch.cat([x, glob.unsqueeze(0).expand(x.shape[0], -1)], dim=-1)
+        x = x.float().contiguous()
+        n = x.shape[0]
+        with torch.no_grad():
+            src, dst, fixed_k = _graph_arrays(g, n)
+            plan = _locality_plan(g, n, fixed_k, src) if (self.locality_sort and fixed_k > 0) else None
+            self._materialize_all(x.shape[1], edge_attr.shape[1])
+            packs = self._train_packs()
+        if plan is not None:
+            order, inv, src, dst = plan
+            x = training.permute_rows(x, order, inv)
+        acc, tr = training.forward_train(self, x, src, dst, fixed_k, packs)
+        if plan is not None:
+            acc = training.permute_rows(acc, inv, order)
+            tr = training.permute_rows(tr, inv, order)
+        return {"acceleration": acc, "temp_rate": tr}
+
     def _forward(self, g, want_latents: bool) -> dict:
-        if _needs_grad(self):
-            raise NotImplementedError(_TRAINING_MSG)
+        if torch.is_grad_enabled() and (_needs_grad(self) or g.x.requires_grad):
+            if want_latents:
+                raise NotImplementedError("forward_with_latents is inference-only: call it under torch.no_grad()")
+            return self._forward_train(g)
         x = g.x
         require_device(x, "input_graph.x")
         edge_attr = getattr(g, "edge_attr", None)

@@ -407,3 +407,86 @@ def scatter_rows(rows: torch.Tensor, idx: torch.Tensor, table: torch.Tensor) -> 
     check(_lib.load().cgnn_scatter_rows(rows.data_ptr(), idx.data_ptr(), idx.numel(), table.shape[1],
                                         table.data_ptr(), stream_ptr(table.device)), "cgnn_scatter_rows")
     return table
+
+
+# ---- backward of the node stream (include/cgnn.h: cgnn_mlp_backward / cgnn_weight_grad / cgnn_col_dot) -----------
+
+class BackwardScratch:
+    """The per-layer activation / gradient matrices ``cgnn_mlp_backward`` leaves behind for the parameter
+    gradients (``cgnn_mlp_bwd_buffers``).  Sized for the widest MLP it will be used with and reused across calls."""
+
+    def __init__(self, n: int, hidden: int, out_padded: int, num_hidden_layers: int, device):
+        self.n, self.hidden, self.out_padded, self.nh = int(n), int(hidden), int(out_padded), int(num_hidden_layers)
+        new = lambda w: torch.empty((self.n, w), dtype=torch.float32, device=device)  # noqa: E731
+        self.h = [new(hidden) for _ in range(self.nh)]
+        self.g_a = [new(hidden) for _ in range(self.nh)]
+        self.g_o = new(out_padded)
+        self.zhat = new(out_padded)
+
+    def struct(self, nh: int, out_padded: int) -> _lib.MlpBwdBuffers:
+        if nh > self.nh or out_padded > self.out_padded:
+            raise CgnnError("BackwardScratch is too small for this MLP")
+        b = _lib.MlpBwdBuffers()
+        for l in range(nh):
+            b.h[l] = self.h[l].data_ptr()
+            b.g_a[l] = self.g_a[l].data_ptr()
+        b.g_o = self.g_o.data_ptr()
+        b.zhat = self.zhat.data_ptr()
+        return b
+
+
+def mlp_backward(fwd: PackedMLP, fwd2: Optional[PackedLinear], bwd: PackedMLP, bwd2: Optional[PackedLinear],
+                 u1: torch.Tensor, u2: Optional[torch.Tensor], dy: torch.Tensor, scratch: BackwardScratch,
+                 want_du1: bool = True, want_du2: bool = True):
+    """Data gradients of ``y = [LN](MLP(cat(u1, u2)))`` given ``dy``; fills ``scratch`` (read it with
+    :func:`weight_grad` / :func:`col_dot` before the next call).  ``bwd`` / ``bwd2`` hold the transposed weights.
+    Returns ``(du1 | None, du2 | None)``.  Note ``scratch.g_o`` / ``scratch.zhat`` rows are ``32*ceil(out/32)`` wide."""
+    u1, dy = f32c(u1, "u1"), f32c(dy, "dy")
+    n = u1.shape[0]
+    if n > scratch.n or fwd.hidden != scratch.hidden:
+        raise CgnnError("mlp_backward: scratch does not fit (rows or hidden width)")
+    if dy.shape != (n, fwd.out_dim):
+        raise CgnnError(f"mlp_backward: dy is {tuple(dy.shape)}, expected {(n, fwd.out_dim)}")
+    if u2 is not None:
+        u2 = f32c(u2, "u2")
+    du1 = torch.empty_like(u1) if want_du1 else None
+    du2 = torch.empty_like(u2) if (want_du2 and u2 is not None) else None
+    out_padded = (fwd.out_dim + 31) // 32 * 32
+    # g_o / zhat are written with a row stride of THIS MLP's padded output width (the scratch is flat memory)
+    bufs = scratch.struct(fwd.num_hidden_layers, out_padded)
+    s_f2 = fwd2.struct() if fwd2 is not None else None
+    s_b2 = bwd2.struct() if bwd2 is not None else None
+    with _timed("mlp_backward", u1.device):
+        check(_lib.load().cgnn_mlp_backward(
+            C.byref(fwd.struct()), C.byref(s_f2) if s_f2 is not None else None, C.byref(bwd.struct()),
+            C.byref(s_b2) if s_b2 is not None else None, u1.data_ptr(), u1.stride(0), ptr(u2),
+            u2.stride(0) if u2 is not None else 0, dy.data_ptr(), dy.stride(0), n, C.byref(bufs), ptr(du1),
+            du1.stride(0) if du1 is not None else 0, ptr(du2), du2.stride(0) if du2 is not None else 0,
+            stream_ptr(u1.device)), "cgnn_mlp_backward")
+    return du1, du2
+
+
+def weight_grad(g: torch.Tensor, ld_g: int, out_dim: int, a: torch.Tensor, in_dim: int, n: int, dw: torch.Tensor,
+                col0: int = 0) -> torch.Tensor:
+    """``dw[:, col0:col0+in_dim] += g[:n, :out_dim]^T a[:n, :in_dim]`` (``dw`` contiguous float32, pre-zeroed by the
+    caller on first use)."""
+    require_device(g, "g")
+    a = f32c(a, "a")
+    if dw.dtype != torch.float32 or not dw.is_contiguous() or dw.shape[0] != out_dim:
+        raise CgnnError("weight_grad: dw must be contiguous float32 [out_dim, >= col0 + in_dim]")
+    with _timed("weight_grad", a.device):
+        check(_lib.load().cgnn_weight_grad(g.data_ptr(), ld_g, out_dim, a.data_ptr(), a.stride(0), in_dim, n,
+                                           dw.data_ptr(), dw.stride(0), col0, stream_ptr(a.device)), "cgnn_weight_grad")
+    return dw
+
+
+def col_dot(a: torch.Tensor, ld_a: int, b: Optional[torch.Tensor], ld_b: int, n: int, width: int,
+            out: torch.Tensor) -> torch.Tensor:
+    """``out[c] += sum_r a[r, c] * (b[r, c] if b is not None else 1)``."""
+    require_device(a, "a")
+    if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() < width:
+        raise CgnnError("col_dot: out must be contiguous float32 [width]")
+    with _timed("col_dot", a.device):
+        check(_lib.load().cgnn_col_dot(a.data_ptr(), ld_a, ptr(b), ld_b, n, width, out.data_ptr(),
+                                       stream_ptr(a.device)), "cgnn_col_dot")
+    return out

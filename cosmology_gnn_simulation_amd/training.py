@@ -1,0 +1,183 @@
+"""Training through the fused kernels: forward + backward of the node stream.
+
+What ``combined_loss.backward()`` of reference train.py:263 actually differentiates: the reference never overrides
+``MessagePassing.message`` (graph_network.py:92-101), so the aggregation sums the *sender node latents* and the edge
+stream never reaches the outputs.  The autograd graph from the loss therefore contains only
+
+    x0 --node encoder--> x_0;   agg_i = sum_{senders} x_i;   x_{i+1} = x_i + LN(MLP_i([x_i, agg_i]));
+    acceleration = dec_acc(x_L),  temp_rate = dec_tr(x_L)
+
+and every edge-model parameter keeps ``grad = None`` under the reference as well.  This module runs exactly that
+graph in exact f32: the training forward skips the (dead) edge stream, keeps ``x_i`` per round, and the backward
+recomputes the activations tile by tile (``cgnn_mlp_backward``), transposes the aggregation with
+``cgnn_aggregate(src <-> dst)`` and reduces the parameter gradients with ``cgnn_weight_grad`` / ``cgnn_col_dot``.
+
+``message_source="edge"`` (the engine's extension, not the reference's behaviour) has no backward yet.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from ._lib import CgnnError
+
+
+class _TrainMLP:
+    """Forward (exact f32) and transposed packings of one ``build_mlp`` (+LayerNorm), plus its parameter list in
+    ``module.parameters()`` order: (w, b) per Linear, then LayerNorm (weight, bias)."""
+
+    def __init__(self, linears: Sequence[nn.Module], ln: Optional[nn.LayerNorm], split_at: Optional[int] = None):
+        self.linears, self.ln = list(linears), ln
+        self.split_at = split_at
+        w0 = linears[0].weight
+        wb = [(l.weight, l.bias) for l in linears]
+        lnp = None if ln is None else (ln.weight, ln.bias)
+        self.in1 = int(split_at if split_at is not None else w0.shape[1])
+        self.in2 = int(w0.shape[1] - self.in1)
+        cols = (0, self.in1) if split_at is not None else None
+        self.fwd = ops.PackedMLP(wb, lnp, "fp32", first_layer_cols=cols)
+        self.fwd2 = ops.PackedLinear(w0, None, "fp32", self.in1, self.in2) if self.in2 else None
+        t = lambda w: w.detach().t().contiguous()  # noqa: E731
+        tw = [(t(w0[:, :self.in1]), None)] + [(t(l.weight), None) for l in linears[1:]]
+        self.bwd = ops.PackedMLP(tw, None, "fp32")
+        self.bwd2 = ops.PackedLinear(t(w0[:, self.in1:]), None, "fp32") if self.in2 else None
+        self.hidden = self.fwd.hidden
+        self.out_dim = self.fwd.out_dim
+        self.out_padded = (self.out_dim + 31) // 32 * 32
+        self.nh = self.fwd.num_hidden_layers
+
+    def params(self) -> List[torch.Tensor]:
+        out: List[torch.Tensor] = []
+        for l in self.linears:
+            out += [l.weight, l.bias]
+        if self.ln is not None:
+            out += [self.ln.weight, self.ln.bias]
+        return out
+
+    def backward(self, u1: torch.Tensor, u2: Optional[torch.Tensor], dy: torch.Tensor, scratch: ops.BackwardScratch,
+                 want_du1: bool, want_du2: bool = True):
+        """-> (du1, du2, [parameter gradients in ``params()`` order])."""
+        n = u1.shape[0]
+        dy = dy.contiguous()
+        du1, du2 = ops.mlp_backward(self.fwd, self.fwd2, self.bwd, self.bwd2, u1, u2, dy, scratch, want_du1, want_du2)
+        grads: List[torch.Tensor] = []
+        H = self.hidden
+        for l, lin in enumerate(self.linears):
+            last = l == self.nh
+            g = scratch.g_o if last else scratch.g_a[l]
+            ld_g = self.out_padded if last else H
+            out_dim = lin.weight.shape[0]
+            dw = torch.zeros_like(lin.weight, memory_format=torch.contiguous_format)
+            if l == 0:
+                ops.weight_grad(g, ld_g, out_dim, u1, self.in1, n, dw, 0)
+                if u2 is not None:
+                    ops.weight_grad(g, ld_g, out_dim, u2, self.in2, n, dw, self.in1)
+            else:
+                ops.weight_grad(g, ld_g, out_dim, scratch.h[l - 1], H, n, dw, 0)
+            db = torch.zeros(out_dim, dtype=torch.float32, device=dw.device)
+            ops.col_dot(g, ld_g, None, 0, n, out_dim, db)
+            grads += [dw, db]
+        if self.ln is not None:
+            dgamma = torch.zeros(self.out_dim, dtype=torch.float32, device=dy.device)
+            dbeta = torch.zeros_like(dgamma)
+            ops.col_dot(dy, dy.stride(0), scratch.zhat, self.out_padded, n, self.out_dim, dgamma)
+            ops.col_dot(dy, dy.stride(0), None, 0, n, self.out_dim, dbeta)
+            grads += [dgamma, dbeta]
+        return du1, du2, grads
+
+
+class TrainPacks:
+    """All node-stream MLPs of an ``EncodeProcessDecode`` packed for training."""
+
+    def __init__(self, model):
+        from .graph_network import _split_mlp
+        D = model._latent_size
+        self.latent = D
+        self.enc = _TrainMLP(*_split_mlp(model.encoder.node_model))
+        self.rounds = [_TrainMLP(*_split_mlp(net.node_model), split_at=D) for net in model.processor]
+        self.dec_acc = _TrainMLP(*_split_mlp(model.decoder_acc))
+        self.dec_tr = _TrainMLP(*_split_mlp(model.decoder_temp_rate))
+        self.all = [self.enc] + self.rounds + [self.dec_acc, self.dec_tr]
+        for m in self.all:
+            if m.hidden != D or m.hidden not in (32, 64, 128):
+                raise CgnnError(f"training kernels are built for mlp_hidden_size == latent_size in (32, 64, 128); got "
+                                f"hidden {m.hidden}, latent {D}")
+        if self.enc.in1 > 32:
+            raise CgnnError(f"training kernels take at most 32 node input features (got {self.enc.in1})")
+        self.nh = self.enc.nh
+
+    def params(self) -> List[torch.Tensor]:
+        return [p for m in self.all for p in m.params()]
+
+
+class _NodeStream(torch.autograd.Function):
+    """acceleration, temp_rate = f(x0; node-stream parameters).  Non-tensor context first, then ``x0`` and the
+    parameters (so autograd routes one gradient to each)."""
+
+    @staticmethod
+    def forward(ctx, packs: TrainPacks, graph, x0: torch.Tensor, *params: torch.Tensor):
+        src, dst, fixed_k = graph
+        n = x0.shape[0]
+        xs = [ops.mlp_rows(packs.enc.fwd, x0)]
+        for r in packs.rounds:
+            x = xs[-1]
+            agg = ops.aggregate(x, src, dst, n, fixed_k, src.numel())
+            xs.append(ops.node_block(r.fwd, r.fwd.layers[0], r.fwd2, x, agg, None, residual=True))
+        acc = ops.mlp_rows(packs.dec_acc.fwd, xs[-1])
+        tr = ops.mlp_rows(packs.dec_tr.fwd, xs[-1])
+        ctx.packs, ctx.graph, ctx.x0, ctx.xs = packs, graph, x0, xs
+        return acc, tr
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_acc, d_tr):
+        packs, (src, dst, fixed_k), x0, xs = ctx.packs, ctx.graph, ctx.x0, ctx.xs
+        n, D = x0.shape[0], packs.latent
+        scratch = ops.BackwardScratch(n, D, max(D, 32), packs.nh, x0.device)
+        grads_of = {}
+        xl = xs[-1]
+        zero = lambda t, w: torch.zeros((n, w), dtype=torch.float32, device=x0.device) if t is None else t  # noqa: E731
+        dx, _, grads_of[id(packs.dec_acc)] = packs.dec_acc.backward(xl, None, zero(d_acc, packs.dec_acc.out_dim),
+                                                                    scratch, True)
+        dx2, _, grads_of[id(packs.dec_tr)] = packs.dec_tr.backward(xl, None, zero(d_tr, packs.dec_tr.out_dim),
+                                                                   scratch, True)
+        dx = dx.add_(dx2)
+        for i in range(len(packs.rounds) - 1, -1, -1):
+            r, x = packs.rounds[i], xs[i]
+            agg = ops.aggregate(x, src, dst, n, fixed_k, src.numel())          # recomputed, not kept
+            du1, du2, grads_of[id(r)] = r.backward(x, agg, dx, scratch, True, True)
+            # x_{i+1} = x_i + f(x_i, agg(x_i)):  dx_i = dx_{i+1} + du1 + A^T du2     (A^T: senders <- receivers)
+            dagg = ops.aggregate(du2, dst, src, n, 0, src.numel())
+            dx = dx.add_(du1).add_(dagg)
+        need_dx0 = ctx.needs_input_grad[2]
+        dx0, _, grads_of[id(packs.enc)] = packs.enc.backward(x0, None, dx, scratch, need_dx0)
+        flat = [g for m in packs.all for g in grads_of[id(m)]]
+        ctx.xs = None
+        return (None, None, dx0, *flat)
+
+
+def forward_train(model, x0: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, fixed_k: int, packs: TrainPacks):
+    """Differentiable ``(acceleration, temp_rate)`` for node features ``x0`` (already float32, contiguous, on the
+    device, in the kernels' particle order)."""
+    return _NodeStream.apply(packs, (src, dst, fixed_k), x0, *packs.params())
+
+
+class _Permute(torch.autograd.Function):
+    """``out = rows[idx]`` for a permutation ``idx`` with inverse ``inv`` (HIP row gather both ways)."""
+
+    @staticmethod
+    def forward(ctx, rows, idx, inv):
+        ctx.inv = inv
+        return ops.gather_rows(rows.contiguous(), idx)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        return ops.gather_rows(d_out.contiguous(), ctx.inv), None, None
+
+
+def permute_rows(rows: torch.Tensor, idx: torch.Tensor, inv: torch.Tensor) -> torch.Tensor:
+    return _Permute.apply(rows, idx, inv)

@@ -182,6 +182,46 @@ int cgnn_node_block(const cgnn_mlp* mlp, const cgnn_linear* w_x, const cgnn_line
                     const cgnn_linear* ws_next, const cgnn_linear* wd_next, int32_t proj_precision,
                     void* ps_next, void* pd_next, int32_t p_format, void* stream);
 
+/* ---- backward of a row-wise MLP (+LayerNorm): the node stream of train.py:263 ------------------------
+ * In reference-faithful mode only the node path carries gradient (the edge models' parameters get
+ * none), so training needs the backward of cgnn_mlp_rows / cgnn_node_block and the transpose of the
+ * aggregation (= cgnn_aggregate with src and dst swapped, general path).  Exact f32 (CGNN_F32) only.
+ *
+ * cgnn_mlp_backward recomputes the forward of one 32-row tile from its inputs (no activations are kept from the
+ * forward pass), then walks the chain backwards:
+ *     y = [LayerNorm](W_nh relu(... relu(W_0a u1 + W_0b u2 + b_0) ...) + b_nh),      given dy = dL/dy
+ * and writes, all row-major f32:
+ *   buf->h[l]    [n, H]        post-ReLU activation of hidden layer l (recomputed)          l = 0..nh-1
+ *   buf->g_a[l]  [n, H]        dL/d(pre-activation of hidden layer l)
+ *   buf->g_o     [n, 32*ceil(out/32)]  dL/d(output layer's pre-LayerNorm output)
+ *   buf->zhat    [n, out]      normalised output (LayerNorm only; else unused)
+ *   du1 / du2                  dL/du1, dL/du2 (either may be NULL when not needed)
+ * The parameter gradients then are plain reductions over rows (cgnn_weight_grad, cgnn_col_dot):
+ *   dW_nh = g_o^T h[nh-1], dW_l = g_a[l]^T h[l-1], dW_0a = g_a[0]^T u1, dW_0b = g_a[0]^T u2, db = column sums,
+ *   dgamma = colsum(dy * zhat), dbeta = colsum(dy).
+ * `fwd` holds the forward weights (layer[0] = W_0a; fwd_part2 = W_0b or NULL), `bwd` the TRANSPOSED weights
+ * packed the same way (bwd->layer[l] = W_l^T, in_dim = out_l, out_dim = in_l; bwd_part2 = W_0b^T or NULL). */
+typedef struct {
+    float* h[CGNN_MAX_HIDDEN_LAYERS];
+    float* g_a[CGNN_MAX_HIDDEN_LAYERS];
+    float* g_o;
+    float* zhat;
+} cgnn_mlp_bwd_buffers;
+
+int cgnn_mlp_backward(const cgnn_mlp* fwd, const cgnn_linear* fwd_part2, const cgnn_mlp* bwd,
+                      const cgnn_linear* bwd_part2, const float* u1, int32_t ld1, const float* u2, int32_t ld2,
+                      const float* dy, int32_t ld_dy, int64_t n, const cgnn_mlp_bwd_buffers* buf,
+                      float* du1, int32_t ld_du1, float* du2, int32_t ld_du2, void* stream);
+
+/* dw[o, col0 + i] += sum_r g[r, o] * a[r, i]   (o < out_dim, i < in_dim; f32 MFMA, float atomics across row chunks:
+ * the caller zeroes dw; summation order over row chunks is not reproducible). */
+int cgnn_weight_grad(const float* g, int32_t ld_g, int32_t out_dim, const float* a, int32_t ld_a, int32_t in_dim,
+                     int64_t n, float* dw, int32_t ld_dw, int32_t col0, void* stream);
+
+/* out[c] += sum_r a[r, c] * (b ? b[r, c] : 1)   for c < width (bias / LayerNorm-affine gradients). */
+int cgnn_col_dot(const float* a, int32_t ld_a, const float* b, int32_t ld_b, int64_t n, int32_t width, float* out,
+                 void* stream);
+
 /* ---- K1+K2+K3: periodic k-NN graph + edge features -----------------------------
  * For each query particle q (all n, or query_ids[0..nq) when non-NULL) the k
  * nearest of the 27 periodic images of all particles, ordered by (float32 squared

@@ -27,6 +27,7 @@ def test_struct_layout_matches_header():
     import ctypes as C
     assert C.sizeof(_lib.Linear) == 24
     assert C.sizeof(_lib.Mlp) == 8 + 7 * 24 + 16
+    assert C.sizeof(_lib.MlpBwdBuffers) == (6 + 6 + 2) * 8
 
 
 def test_state_dict_contract_and_load_before_forward():
@@ -49,10 +50,16 @@ def test_no_cpu_fallback():
         m(g)
 
 
-def test_training_mode_is_refused_loudly():
-    m = graph_network.EncodeProcessDecode(32, 32, 2, 1, 3)
+def test_training_paths_without_backward_kernels_are_refused_loudly():
     g = Data(x=torch.zeros(4, 17), edge_index=torch.zeros(2, 8, dtype=torch.long), edge_attr=torch.zeros(8, 4))
+    m = graph_network.EncodeProcessDecode(32, 32, 2, 1, 3)
+    m.message_source = "edge"                  # the engine's extension has no backward
     with pytest.raises(NotImplementedError):
+        m(g)
+    with pytest.raises(NotImplementedError):   # stand-alone sub-modules are inference-only
+        m.encoder(g)
+    m.message_source = "x_j"
+    with pytest.raises(_lib.CgnnError):        # training exists, but only on the device: no CPU path
         m(g)
 
 
