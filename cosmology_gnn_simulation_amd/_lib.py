@@ -28,7 +28,8 @@ EXPORTS = (
     "cgnn_mlp_rows", "cgnn_project_nodes", "cgnn_edge_block", "cgnn_aggregate", "cgnn_node_block",
     "cgnn_knn_workspace_bytes", "cgnn_knn_periodic", "cgnn_knn_sorted_order", "cgnn_segment_colsum",
     "cgnn_gather_rows", "cgnn_scatter_rows", "cgnn_tiled_rows", "cgnn_relayout", "cgnn_window_features",
-    "cgnn_mlp_backward", "cgnn_weight_grad", "cgnn_col_dot",
+    "cgnn_mlp_backward", "cgnn_weight_grad", "cgnn_col_dot", "cgnn_csr_workspace_bytes", "cgnn_csr_build",
+    "cgnn_aggregate_csr",
 )
 ROWS, TILED32 = 0, 1
 
@@ -92,7 +93,11 @@ def load() -> C.CDLL:
     lib.cgnn_scatter_rows.argtypes = [vp, vp, i64, i32, vp, vp]
     lib.cgnn_mlp_backward.argtypes = [C.POINTER(Mlp), C.POINTER(Linear), C.POINTER(Mlp), C.POINTER(Linear), vp, i32, vp,
                                       i32, vp, i32, i64, C.POINTER(MlpBwdBuffers), vp, i32, vp, i32, vp]
-    lib.cgnn_weight_grad.argtypes = [vp, i32, i32, vp, i32, i32, i64, vp, i32, i32, vp]
+    lib.cgnn_weight_grad.argtypes = [vp, i32, i32, vp, i32, i32, i64, vp, i32, i32, vp, vp]
+    lib.cgnn_csr_workspace_bytes.restype = sz
+    lib.cgnn_csr_workspace_bytes.argtypes = [i64]
+    lib.cgnn_csr_build.argtypes = [vp, vp, i64, i64, vp, vp, vp, sz, vp]
+    lib.cgnn_aggregate_csr.argtypes = [vp, vp, vp, i64, i32, vp, vp]
     lib.cgnn_col_dot.argtypes = [vp, i32, vp, i32, i64, i32, vp, vp]
     missing = [name for name in EXPORTS if not hasattr(lib, name)]
     if missing:

@@ -179,56 +179,124 @@ __global__ __launch_bounds__(CGNN_BLOCK) void mlp_backward_kernel(
     }
 }
 
-// dw[o, col0+i] += sum_r g[r,o] a[r,i]: one 32x32 output tile per wave over a chunk of rows.
-#define CGNN_WGRAD_ROWS 4096
+// dw[o, col0+i] += sum_r g[r,o] a[r,i] (and db[o] += sum_r g[r,o]): per workgroup one chunk of rows; each wave
+// owns one 32-wide slab of g's columns (an output tile) against G 32-wide slabs of a at once, so g is read once
+// per G input tiles and the column sums of g -- the bias gradient -- fall out of the A operands already loaded.
+#define CGNN_WGRAD_ROWS 1024
+template <int G>
 __global__ __launch_bounds__(CGNN_BLOCK) void weight_grad_kernel(const float* __restrict__ g, int ld_g, int out_dim,
                                                                  const float* __restrict__ a, int ld_a, int in_dim,
-                                                                 int64_t n, int it_tiles, int n_tiles,
-                                                                 float* __restrict__ dw, int ld_dw, int col0) {
+                                                                 int64_t n, int it_groups, int n_items,
+                                                                 float* __restrict__ dw, int ld_dw, int col0,
+                                                                 float* __restrict__ db) {
     const int lane = threadIdx.x & 63, i = lane & 31, kk = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int t = blockIdx.y * CGNN_WAVES_PER_BLOCK + wave;
-    if (t >= n_tiles) return;
-    const int ot = t / it_tiles, it = t % it_tiles;
+    const int item = blockIdx.y * CGNN_WAVES_PER_BLOCK + wave;
+    if (item >= n_items) return;
+    const int ot = item / it_groups, ig = item % it_groups;
     const int64_t r0 = (int64_t)blockIdx.x * CGNN_WGRAD_ROWS;
     const int64_t r1 = r0 + CGNN_WGRAD_ROWS < n ? r0 + CGNN_WGRAD_ROWS : n;
-    const int oc = 32 * ot + i, ic = 32 * it + i;
-    const bool o_ok = oc < out_dim, i_ok = ic < in_dim;
-    f32x16 acc;
+    const int oc = 32 * ot + i;
+    const bool o_ok = oc < out_dim;
+    bool i_ok[G];
 #pragma unroll
-    for (int x = 0; x < 16; ++x) acc[x] = 0.f;
-    for (int64_t rr = r0; rr < r1; rr += 16) {
-        float av[8], bv[8];
+    for (int q = 0; q < G; ++q) i_ok[q] = 32 * (ig * G + q) + i < in_dim;
+    const float* gp = g + oc;
+    const float* ap = a + 32 * ig * G + i;
+    f32x16 acc[G];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+    for (int q = 0; q < G; ++q)
+#pragma unroll
+        for (int x = 0; x < 16; ++x) acc[q][x] = 0.f;
+    float colsum = 0.f;
+    for (int64_t rr = r0; rr < r1; rr += 8) {
+        float av[4], bv[G][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
             const int64_t row = rr + 2 * s + kk;
             const bool ok = row < r1;
-            av[s] = (ok && o_ok) ? g[row * ld_g + oc] : 0.f;
-            bv[s] = (ok && i_ok) ? a[row * ld_a + ic] : 0.f;
+            av[s] = (ok && o_ok) ? gp[row * ld_g] : 0.f;
+#pragma unroll
+            for (int q = 0; q < G; ++q) bv[q][s] = (ok && i_ok[q]) ? ap[row * ld_a + 32 * q] : 0.f;
         }
 #pragma unroll
-        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
-    }
-    // D[row i'][col j]: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+        for (int s = 0; s < 4; ++s) {
+            colsum += av[s];
 #pragma unroll
-    for (int x = 0; x < 16; ++x) {
-        const int o = 32 * ot + (x & 3) + 8 * (x >> 2) + 4 * kk;
-        if (o < out_dim && i_ok) atomicAdd(dw + (int64_t)o * ld_dw + col0 + ic, acc[x]);
+            for (int q = 0; q < G; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[q][s], acc[q], 0, 0, 0);
+        }
+    }
+    // D[row][col]: col = lane & 31 (input column), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (output row)
+#pragma unroll
+    for (int q = 0; q < G; ++q)
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+            const int o = 32 * ot + (x & 3) + 8 * (x >> 2) + 4 * kk;
+            if (o < out_dim && i_ok[q]) atomicAdd(dw + (int64_t)o * ld_dw + col0 + 32 * (ig * G + q) + i, acc[q][x]);
+        }
+    if (db != nullptr && ig == 0) {
+        colsum += __shfl_xor(colsum, 32);
+        if (kk == 0 && o_ok) atomicAdd(db + oc, colsum);
     }
 }
 
-#define CGNN_COLDOT_ROWS 2048
-__global__ void col_dot_kernel(const float* __restrict__ a, int ld_a, const float* __restrict__ b, int ld_b, int64_t n,
-                               int width, float* __restrict__ out) {
+// out[c] += sum_r a[r,c] (* b[r,c]): lanes take 4 columns x 1 row each (16-byte loads when aligned), the row lanes
+// of a workgroup meet in LDS, one atomic per column per workgroup.
+#define CGNN_COLDOT_ROWS 512
+__global__ __launch_bounds__(CGNN_BLOCK) void col_dot_kernel(const float* __restrict__ a, int ld_a,
+                                                             const float* __restrict__ b, int ld_b, int64_t n,
+                                                             int width, float* __restrict__ out) {
+    __shared__ float red[CGNN_BLOCK][4];
+    const int c4n = (width + 3) / 4;                 // 4-column groups (<= 64 handled per pass)
     const int64_t r0 = (int64_t)blockIdx.x * CGNN_COLDOT_ROWS;
     const int64_t r1 = r0 + CGNN_COLDOT_ROWS < n ? r0 + CGNN_COLDOT_ROWS : n;
-    for (int c = threadIdx.x; c < width; c += blockDim.x) {
-        float s = 0.f;
-        if (b != nullptr)
-            for (int64_t r = r0; r < r1; ++r) s += a[r * ld_a + c] * b[r * ld_b + c];
-        else
-            for (int64_t r = r0; r < r1; ++r) s += a[r * ld_a + c];
-        atomicAdd(out + c, s);
+    const bool vec = (width % 4 == 0) && (ld_a % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0) &&
+                     (b == nullptr || ((ld_b % 4 == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0)));
+    for (int c0 = 0; c0 < c4n; c0 += 64) {
+        const int groups = (c4n - c0) < 64 ? (c4n - c0) : 64;      // column groups this pass
+        int cols = 1;
+        while (cols < groups) cols <<= 1;                          // lanes per row (power of two <= 64)
+        const int rl = CGNN_BLOCK / cols;                          // row lanes
+        const int cg = threadIdx.x % cols, rlane = threadIdx.x / cols;
+        const int c = 4 * (c0 + cg);
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        if (cg < groups) {
+            for (int64_t r = r0 + rlane; r < r1; r += rl) {
+                float va[4], vb[4] = {1.f, 1.f, 1.f, 1.f};
+                if (vec) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(a + r * ld_a + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) va[j] = t[j];
+                    if (b != nullptr) {
+                        const f32x4 u = *reinterpret_cast<const f32x4*>(b + r * ld_b + c);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) vb[j] = u[j];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        va[j] = c + j < width ? a[r * ld_a + c + j] : 0.f;
+                        if (b != nullptr) vb[j] = c + j < width ? b[r * ld_b + c + j] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[j] += va[j] * vb[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[threadIdx.x][j] = s[j];
+        __syncthreads();
+        for (int off = rl / 2; off > 0; off >>= 1) {
+            if (rlane < off)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) red[threadIdx.x][j] += red[threadIdx.x + off * cols][j];
+            __syncthreads();
+        }
+        if (rlane == 0 && cg < groups)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c + j < width) atomicAdd(out + c + j, red[threadIdx.x][j]);
+        __syncthreads();
     }
 }
 
@@ -328,7 +396,7 @@ int cgnn_mlp_backward(const cgnn_mlp* fwd, const cgnn_linear* fwd_part2, const c
 }
 
 int cgnn_weight_grad(const float* g, int32_t ld_g, int32_t out_dim, const float* a, int32_t ld_a, int32_t in_dim,
-                     int64_t n, float* dw, int32_t ld_dw, int32_t col0, void* stream) {
+                     int64_t n, float* dw, int32_t ld_dw, int32_t col0, float* db, void* stream) {
     if (!g || !a || !dw || out_dim <= 0 || in_dim <= 0 || n < 0 || ld_g < out_dim || ld_a < in_dim ||
         ld_dw < col0 + in_dim || col0 < 0) {
         set_error("cgnn_weight_grad: invalid argument");
@@ -336,11 +404,21 @@ int cgnn_weight_grad(const float* g, int32_t ld_g, int32_t out_dim, const float*
     }
     if (n == 0) return CGNN_OK;
     const int ot = (out_dim + 31) / 32, it = (in_dim + 31) / 32;
-    const int n_tiles = ot * it;
+    const int G = it >= 4 ? 4 : (it >= 2 ? 2 : 1);
+    const int it_groups = (it + G - 1) / G;
+    const int n_items = ot * it_groups;
     dim3 grid((unsigned)((n + CGNN_WGRAD_ROWS - 1) / CGNN_WGRAD_ROWS),
-              (unsigned)((n_tiles + CGNN_WAVES_PER_BLOCK - 1) / CGNN_WAVES_PER_BLOCK));
-    weight_grad_kernel<<<grid, CGNN_BLOCK, 0, (hipStream_t)stream>>>(g, ld_g, out_dim, a, ld_a, in_dim, n, it, n_tiles,
-                                                                    dw, ld_dw, col0);
+              (unsigned)((n_items + CGNN_WAVES_PER_BLOCK - 1) / CGNN_WAVES_PER_BLOCK));
+    hipStream_t st = (hipStream_t)stream;
+    if (G == 4)
+        weight_grad_kernel<4><<<grid, CGNN_BLOCK, 0, st>>>(g, ld_g, out_dim, a, ld_a, in_dim, n, it_groups, n_items, dw,
+                                                           ld_dw, col0, db);
+    else if (G == 2)
+        weight_grad_kernel<2><<<grid, CGNN_BLOCK, 0, st>>>(g, ld_g, out_dim, a, ld_a, in_dim, n, it_groups, n_items, dw,
+                                                           ld_dw, col0, db);
+    else
+        weight_grad_kernel<1><<<grid, CGNN_BLOCK, 0, st>>>(g, ld_g, out_dim, a, ld_a, in_dim, n, it_groups, n_items, dw,
+                                                           ld_dw, col0, db);
     return check_hip(hipGetLastError(), "cgnn_weight_grad launch");
 }
 

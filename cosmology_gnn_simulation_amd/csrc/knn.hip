@@ -14,6 +14,7 @@
 // image index = shift_id * N + particle, shift_id in cartesian_prod order
 // (x slowest; the centre is 13).  The query itself therefore comes first.
 #include "cgnn_common.hpp"
+#include "scan.hpp"
 
 namespace cgnn {
 
@@ -25,7 +26,6 @@ struct KnnLayout {
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-#define CGNN_SCAN_ITEMS 2048  // per block (256 threads x 8)
 
 static KnnLayout knn_layout(int64_t n) {
     KnnLayout L;
@@ -78,64 +78,6 @@ __global__ void knn_count_kernel(const float* __restrict__ pos, int64_t n, float
     const int cell = morton3(cx, cy, cz);
     cell_of[i] = cell;
     atomicAdd(&count[cell], 1);
-}
-
-// ---- exclusive scan of `count[0..m)` into `start[0..m)` (three small kernels) ----
-__global__ void scan_block_sums_kernel(const int32_t* __restrict__ in, int64_t m, int32_t* __restrict__ bsum) {
-    __shared__ int red[CGNN_BLOCK];
-    const int64_t base = (int64_t)blockIdx.x * CGNN_SCAN_ITEMS;
-    int s = 0;
-    for (int j = 0; j < CGNN_SCAN_ITEMS / CGNN_BLOCK; ++j) {
-        const int64_t i = base + j * CGNN_BLOCK + threadIdx.x;
-        if (i < m) s += in[i];
-    }
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = CGNN_BLOCK / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) bsum[blockIdx.x] = red[0];
-}
-
-__global__ void scan_block_offsets_kernel(int32_t* __restrict__ bsum, int nblk) {
-    // single thread block, serial over <= 8193 entries: negligible
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        int run = 0;
-        for (int i = 0; i < nblk; ++i) {
-            const int v = bsum[i];
-            bsum[i] = run;
-            run += v;
-        }
-    }
-}
-
-__global__ void scan_apply_kernel(const int32_t* __restrict__ in, int64_t m, const int32_t* __restrict__ bsum,
-                                  int32_t* __restrict__ out) {
-    __shared__ int part[CGNN_BLOCK];
-    const int64_t base = (int64_t)blockIdx.x * CGNN_SCAN_ITEMS + (int64_t)threadIdx.x * (CGNN_SCAN_ITEMS / CGNN_BLOCK);
-    int v[CGNN_SCAN_ITEMS / CGNN_BLOCK];
-    int s = 0;
-#pragma unroll
-    for (int j = 0; j < CGNN_SCAN_ITEMS / CGNN_BLOCK; ++j) {
-        v[j] = (base + j < m) ? in[base + j] : 0;
-        s += v[j];
-    }
-    part[threadIdx.x] = s;
-    __syncthreads();
-    // Hillis-Steele inclusive scan of the 256 per-thread totals
-    for (int off = 1; off < CGNN_BLOCK; off <<= 1) {
-        int t = ((int)threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += t;
-        __syncthreads();
-    }
-    int run = bsum[blockIdx.x] + part[threadIdx.x] - s;
-#pragma unroll
-    for (int j = 0; j < CGNN_SCAN_ITEMS / CGNN_BLOCK; ++j) {
-        if (base + j < m) out[base + j] = run;
-        run += v[j];
-    }
 }
 
 __global__ void knn_fill_kernel(const float* __restrict__ pos, int64_t n, const int32_t* __restrict__ cell_of,
@@ -332,10 +274,7 @@ int cgnn_knn_periodic(const float* pos, int64_t n, float box_size, int32_t k, co
     if (rc) return rc;
     const unsigned nb = (unsigned)((n + CGNN_BLOCK - 1) / CGNN_BLOCK);
     knn_count_kernel<<<nb, CGNN_BLOCK, 0, st>>>(pos, n, inv_h, G, cell_of, count);
-    const int sblk = (int)((m + CGNN_SCAN_ITEMS - 1) / CGNN_SCAN_ITEMS);
-    scan_block_sums_kernel<<<sblk, CGNN_BLOCK, 0, st>>>(count, m, bsum);
-    scan_block_offsets_kernel<<<1, 64, 0, st>>>(bsum, sblk);
-    scan_apply_kernel<<<sblk, CGNN_BLOCK, 0, st>>>(count, m, bsum, start);
+    exclusive_scan_i32(count, m, bsum, start, st);
     knn_fill_kernel<<<nb, CGNN_BLOCK, 0, st>>>(pos, n, cell_of, start, cursor, sorted);
     rc = check_hip(hipGetLastError(), "cgnn_knn_periodic build launches");
     if (rc) return rc;

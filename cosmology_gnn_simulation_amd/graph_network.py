@@ -443,7 +443,14 @@ class EncodeProcessDecode(nn.Module):
         if plan is not None:
             order, inv, src, dst = plan
             x = training.permute_rows(x, order, inv)
-        acc, tr = training.forward_train(self, x, src, dst, fixed_k, packs)
+        cached = getattr(g, "_cgnn_by_sender", None)      # transposed adjacency, once per graph
+        if cached is None or cached[0] is not src:
+            cached = (src, ops.SenderCsr(src, dst, n))
+            try:
+                g._cgnn_by_sender = cached
+            except Exception:
+                pass
+        acc, tr = training.forward_train(self, x, src, dst, fixed_k, packs, cached[1])
         if plan is not None:
             acc = training.permute_rows(acc, inv, order)
             tr = training.permute_rows(tr, inv, order)

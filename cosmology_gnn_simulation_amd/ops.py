@@ -467,17 +467,51 @@ def mlp_backward(fwd: PackedMLP, fwd2: Optional[PackedLinear], bwd: PackedMLP, b
 
 
 def weight_grad(g: torch.Tensor, ld_g: int, out_dim: int, a: torch.Tensor, in_dim: int, n: int, dw: torch.Tensor,
-                col0: int = 0) -> torch.Tensor:
+                col0: int = 0, db: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``dw[:, col0:col0+in_dim] += g[:n, :out_dim]^T a[:n, :in_dim]`` (``dw`` contiguous float32, pre-zeroed by the
-    caller on first use)."""
+    caller on first use); ``db`` (optional, pre-zeroed) ``+= `` the column sums of ``g``."""
     require_device(g, "g")
     a = f32c(a, "a")
     if dw.dtype != torch.float32 or not dw.is_contiguous() or dw.shape[0] != out_dim:
         raise CgnnError("weight_grad: dw must be contiguous float32 [out_dim, >= col0 + in_dim]")
     with _timed("weight_grad", a.device):
         check(_lib.load().cgnn_weight_grad(g.data_ptr(), ld_g, out_dim, a.data_ptr(), a.stride(0), in_dim, n,
-                                           dw.data_ptr(), dw.stride(0), col0, stream_ptr(a.device)), "cgnn_weight_grad")
+                                           dw.data_ptr(), dw.stride(0), col0, ptr(db), stream_ptr(a.device)),
+              "cgnn_weight_grad")
     return dw
+
+
+class SenderCsr:
+    """Edges grouped by ``key`` (``cgnn_csr_build``): ``row_ptr`` int32 [rows + 1], ``col`` int32 [E]."""
+
+    def __init__(self, key: torch.Tensor, val: Optional[torch.Tensor], num_rows: int):
+        lib = _lib.load()
+        key = i32c(key, "key")
+        ne = key.numel()
+        if val is not None:
+            val = i32c(val, "val")
+            if val.numel() != ne:
+                raise CgnnError("SenderCsr: key and val differ in length")
+        self.rows = int(num_rows)
+        self.row_ptr = torch.empty(self.rows + 1, dtype=torch.int32, device=key.device)
+        self.col = torch.empty(max(ne, 1), dtype=torch.int32, device=key.device)
+        nbytes = lib.cgnn_csr_workspace_bytes(self.rows)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=key.device)
+        with _timed("csr_build", key.device):
+            check(lib.cgnn_csr_build(key.data_ptr(), ptr(val), ne, self.rows, self.row_ptr.data_ptr(),
+                                     self.col.data_ptr(), ws.data_ptr(), nbytes, stream_ptr(key.device)), "cgnn_csr_build")
+
+
+def aggregate_csr(table: torch.Tensor, csr: SenderCsr, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``out[r] = sum_{p in row r} table[csr.col[p]]``."""
+    table = f32c(table, "table")
+    if out is None:
+        out = torch.empty((csr.rows, table.shape[1]), dtype=torch.float32, device=table.device)
+    with _timed("aggregate_csr", table.device):
+        check(_lib.load().cgnn_aggregate_csr(table.data_ptr(), csr.row_ptr.data_ptr(), csr.col.data_ptr(), csr.rows,
+                                             table.shape[1], out.data_ptr(), stream_ptr(table.device)),
+              "cgnn_aggregate_csr")
+    return out
 
 
 def col_dot(a: torch.Tensor, ld_a: int, b: Optional[torch.Tensor], ld_b: int, n: int, width: int,

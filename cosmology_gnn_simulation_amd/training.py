@@ -9,8 +9,9 @@ stream never reaches the outputs.  The autograd graph from the loss 
 
 and every edge-model parameter keeps ``grad = None`` under the reference as well.  This module runs exactly that
 graph in exact f32: the training forward skips the (dead) edge stream, keeps ``x_i`` per round, and the backward
-recomputes the activations tile by tile (``cgnn_mlp_backward``), transposes the aggregation with
-``cgnn_aggregate(src <-> dst)`` and reduces the parameter gradients with ``cgnn_weight_grad`` / ``cgnn_col_dot``.
+recomputes the activations tile by tile (``cgnn_mlp_backward``), transposes the aggregation by gathering through
+the sender-major adjacency (``cgnn_csr_build`` once per graph, ``cgnn_aggregate_csr``) and reduces the parameter
+gradients with ``cgnn_weight_grad`` / ``cgnn_col_dot``.
 
 ``message_source="edge"`` (the engine's extension, not the reference's behaviour) has no backward yet.
 """
@@ -71,14 +72,13 @@ class _TrainMLP:
             ld_g = self.out_padded if last else H
             out_dim = lin.weight.shape[0]
             dw = torch.zeros_like(lin.weight, memory_format=torch.contiguous_format)
+            db = torch.zeros(out_dim, dtype=torch.float32, device=dw.device)
             if l == 0:
-                ops.weight_grad(g, ld_g, out_dim, u1, self.in1, n, dw, 0)
+                ops.weight_grad(g, ld_g, out_dim, u1, self.in1, n, dw, 0, db)
                 if u2 is not None:
                     ops.weight_grad(g, ld_g, out_dim, u2, self.in2, n, dw, self.in1)
             else:
-                ops.weight_grad(g, ld_g, out_dim, scratch.h[l - 1], H, n, dw, 0)
-            db = torch.zeros(out_dim, dtype=torch.float32, device=dw.device)
-            ops.col_dot(g, ld_g, None, 0, n, out_dim, db)
+                ops.weight_grad(g, ld_g, out_dim, scratch.h[l - 1], H, n, dw, 0, db)
             grads += [dw, db]
         if self.ln is not None:
             dgamma = torch.zeros(self.out_dim, dtype=torch.float32, device=dy.device)
@@ -119,7 +119,7 @@ class _NodeStream(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, packs: TrainPacks, graph, x0: torch.Tensor, *params: torch.Tensor):
-        src, dst, fixed_k = graph
+        src, dst, fixed_k, _ = graph
         n = x0.shape[0]
         xs = [ops.mlp_rows(packs.enc.fwd, x0)]
         for r in packs.rounds:
@@ -134,7 +134,7 @@ class _NodeStream(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_acc, d_tr):
-        packs, (src, dst, fixed_k), x0, xs = ctx.packs, ctx.graph, ctx.x0, ctx.xs
+        packs, (src, dst, fixed_k, by_sender), x0, xs = ctx.packs, ctx.graph, ctx.x0, ctx.xs
         n, D = x0.shape[0], packs.latent
         scratch = ops.BackwardScratch(n, D, max(D, 32), packs.nh, x0.device)
         grads_of = {}
@@ -150,7 +150,7 @@ class _NodeStream(torch.autograd.Function):
             agg = ops.aggregate(x, src, dst, n, fixed_k, src.numel())          # recomputed, not kept
             du1, du2, grads_of[id(r)] = r.backward(x, agg, dx, scratch, True, True)
             # x_{i+1} = x_i + f(x_i, agg(x_i)):  dx_i = dx_{i+1} + du1 + A^T du2     (A^T: senders <- receivers)
-            dagg = ops.aggregate(du2, dst, src, n, 0, src.numel())
+            dagg = ops.aggregate_csr(du2, by_sender)
             dx = dx.add_(du1).add_(dagg)
         need_dx0 = ctx.needs_input_grad[2]
         dx0, _, grads_of[id(packs.enc)] = packs.enc.backward(x0, None, dx, scratch, need_dx0)
@@ -159,10 +159,12 @@ class _NodeStream(torch.autograd.Function):
         return (None, None, dx0, *flat)
 
 
-def forward_train(model, x0: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, fixed_k: int, packs: TrainPacks):
+def forward_train(model, x0: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, fixed_k: int, packs: TrainPacks,
+                  by_sender: "ops.SenderCsr"):
     """Differentiable ``(acceleration, temp_rate)`` for node features ``x0`` (already float32, contiguous, on the
-    device, in the kernels' particle order)."""
-    return _NodeStream.apply(packs, (src, dst, fixed_k), x0, *packs.params())
+    device, in the kernels' particle order).  ``by_sender``: ``ops.SenderCsr(src, dst, n)``, the transposed
+    adjacency the backward of the aggregation gathers through."""
+    return _NodeStream.apply(packs, (src, dst, fixed_k, by_sender), x0, *packs.params())
 
 
 class _Permute(torch.autograd.Function):

@@ -214,13 +214,27 @@ int cgnn_mlp_backward(const cgnn_mlp* fwd, const cgnn_linear* fwd_part2, const c
                       float* du1, int32_t ld_du1, float* du2, int32_t ld_du2, void* stream);
 
 /* dw[o, col0 + i] += sum_r g[r, o] * a[r, i]   (o < out_dim, i < in_dim; f32 MFMA, float atomics across row chunks:
- * the caller zeroes dw; summation order over row chunks is not reproducible). */
+ * the caller zeroes dw; summation order over row chunks is not reproducible).  db (optional): db[o] += sum_r g[r, o],
+ * the bias gradient, from the operands already loaded. */
 int cgnn_weight_grad(const float* g, int32_t ld_g, int32_t out_dim, const float* a, int32_t ld_a, int32_t in_dim,
-                     int64_t n, float* dw, int32_t ld_dw, int32_t col0, void* stream);
+                     int64_t n, float* dw, int32_t ld_dw, int32_t col0, float* db, void* stream);
 
 /* out[c] += sum_r a[r, c] * (b ? b[r, c] : 1)   for c < width (bias / LayerNorm-affine gradients). */
 int cgnn_col_dot(const float* a, int32_t ld_a, const float* b, int32_t ld_b, int64_t n, int32_t width, float* out,
                  void* stream);
+
+/* ---- transpose of the aggregation (backward of graph_network.py:92 `propagate`) --------------------------------
+ * cgnn_csr_build groups an edge list by `key`: row_ptr[r]..row_ptr[r+1] delimit, in col[], the `val` (or, when val
+ * is NULL, the edge index) of every edge whose key is r, in ascending order (deterministic).  With key = senders and
+ * val = receivers this is the sender-major adjacency; cgnn_aggregate_csr then sums, for every sender, the rows of its
+ * receivers: out[r] = sum_{p in row} table[col[p]] -- an atomic-free gather like the forward, summed in a fixed order.
+ * row_ptr: num_rows + 1 ints; col: num_edges ints; workspace: cgnn_csr_workspace_bytes(num_rows).  cgnn_csr_build
+ * validates the keys and therefore synchronises the stream once (it runs once per graph). */
+size_t cgnn_csr_workspace_bytes(int64_t num_rows);
+int cgnn_csr_build(const int32_t* key, const int32_t* val, int64_t num_edges, int64_t num_rows, int32_t* row_ptr,
+                   int32_t* col, void* workspace, size_t workspace_bytes, void* stream);
+int cgnn_aggregate_csr(const float* table, const int32_t* row_ptr, const int32_t* col, int64_t num_rows, int32_t width,
+                       float* out, void* stream);
 
 /* ---- K1+K2+K3: periodic k-NN graph + edge features -----------------------------
  * For each query particle q (all n, or query_ids[0..nq) when non-NULL) the k
