@@ -483,7 +483,8 @@ struct PRow<CGNN_BF16> {
 };
 
 // CGNN_P_BF16_S16 rows written from the 32-row act layout (the projection kernel keeps 32-row tiles): lane (r, h)
-// holds features 32t + 8g + 4h + c, which is 16-tile O = 2t + (g >> 1), quarter q = 2 (g & 1) + h, element c.
+// holds features 32t + 8g + 4h + c, which is k-step s = t, quarter q = 2 (g & 1) + h, element j = 4 (g >> 1) + c of the
+// N16 B-operand order: 16-byte element (4 s + q) of the row (n16.hpp, load_p16_operand).
 template <int HT>
 __device__ __forceinline__ void store_prow_s16(const f32x16 (&acc)[HT], __bf16* __restrict__ base, int64_t row, int h) {
     __bf16* rp = base + row * (32 * HT);
@@ -491,11 +492,11 @@ __device__ __forceinline__ void store_prow_s16(const f32x16 (&acc)[HT], __bf16* 
     for (int t = 0; t < HT; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int O = 2 * t + (g >> 1), q = 2 * (g & 1) + h;
+            const int q = 2 * (g & 1) + h;
             bf16x4 v;
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = (__bf16)acc[t][4 * g + c];
-            *reinterpret_cast<bf16x4*>(rp + q * (8 * HT) + 4 * O) = v;
+            *reinterpret_cast<bf16x4*>(rp + (4 * t + q) * 8 + 4 * (g >> 1)) = v;
         }
 }
 

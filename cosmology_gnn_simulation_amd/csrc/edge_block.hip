@@ -8,9 +8,11 @@
 // edges; the edge latent tile is loaded once, kept in registers for the residual,
 // and written once.  The edge-latent tensors are in the TILED32 layout (include/cgnn.h): every tile moves
 // with lane-linear, fully coalesced 16-byte accesses.
+#include <stdlib.h>
 #include <string.h>
 
 #include "mlp_device.hpp"
+
 #include "n16.hpp"
 
 namespace cgnn {
@@ -128,8 +130,8 @@ static int launch_edge_lds(const MlpDev& m, size_t lds, const __bf16* ps, const 
 #endif
 // N16 variant (weights packed CGNN_BF16_N16, P tables CGNN_P_BF16_S16): 16 edges per wave, see n16.hpp.  The
 // f32 tile is read once, kept in registers for the residual, and written once.
-template <int HT, int DT>
-__global__ __launch_bounds__(CGNN_EDGE_N16_BLOCK) void edge_block_n16_kernel(
+template <int HT, int DT, int BLOCK, bool AGG>
+__global__ __launch_bounds__(BLOCK) void edge_block_n16_kernel(
     MlpDev m, const __bf16* __restrict__ ps, const __bf16* __restrict__ pd, const int32_t* __restrict__ src,
     const int32_t* __restrict__ dst, int64_t num_edges, const float* e_in, float* e_out, float* e_upd, int residual,
     const float* __restrict__ x_gather, float* __restrict__ agg_out, int seg_k) {
@@ -138,22 +140,38 @@ __global__ __launch_bounds__(CGNN_EDGE_N16_BLOCK) void edge_block_n16_kernel(
     constexpr int D = 32 * DT, DO = 2 * DT, HO = 2 * HT;     // DO / HO: 16-feature tiles
     const int64_t tiles = (num_edges + 15) / 16;
     const TileRange tr = tile_range(tiles);
+    const bf16x8 sel0 = p16_selector(lane, 0), sel1 = p16_selector(lane, 1);
     for (int64_t tile = tr.first; tile < tr.end; tile += tr.stride) {
         const int64_t e = tile * 16 + c;
         const int64_t ec = e < num_edges ? e : num_edges - 1;
         const int64_t s = src[ec], d = dst[ec];
+#ifdef CGNN_ABLATE_STREAM   // developer ablation: same instructions, the tile stream stays in L2
+        const int64_t tbase = ((tile & 255) >> 1) * (32 * D) + n16_lane_offset(c, q, (int)(tile & 1));
+#else
         const int64_t tbase = (tile >> 1) * (32 * D) + n16_lane_offset(c, q, (int)(tile & 1));
+#endif
         f32x4 ev[DO];
 #pragma unroll
         for (int o = 0; o < DO; ++o)   // streamed once: non-temporal, so that the P-table rows keep their L2 lines
             ev[o] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(e_in + tbase + n16_tile_offset(o)));
+        bf16x8 pso[HT], pdo[HT];
+        load_p16_operand<HT>(pso, ps, s, q);
+        load_p16_operand<HT>(pdo, pd, d, q);
+        f32x4 out[DO];
+#ifdef CGNN_ABLATE_REPEAT   // developer ablation: REPEAT rounds on the tile in registers (compute rate without the stream)
+#pragma nounroll
+        for (int rep = 0; rep < CGNN_ABLATE_REPEAT; ++rep) {
+        if (rep > 0) {
+#pragma unroll
+            for (int o = 0; o < DO; ++o) ev[o] += out[o];
+        }
+#endif
         bf16x8 oph[HT];
         {
             bf16x8 op[DT];
             operand16<false, DT>(op, ev);
             f32x4 acc[HO];
-            load_p16<HO, false>(acc, ps, s, q);
-            load_p16<HO, true>(acc, pd, d, q);
+            p16_accumulate<HT>(acc, pso, pdo, sel0, sel1);
             dense16<DT, HO, CGNN_EDGE_N16_GS>(acc, op, WSel<CGNN_BF16, true>::get(m, 0), lane);
             operand16<true, HT>(oph, acc);
         }
@@ -163,15 +181,17 @@ __global__ __launch_bounds__(CGNN_EDGE_N16_BLOCK) void edge_block_n16_kernel(
             dense16<HT, HO, CGNN_EDGE_N16_GS>(acc, oph, WSel<CGNN_BF16, true>::get(m, l), lane);
             operand16<true, HT>(oph, acc);
         }
-        f32x4 out[DO];
         fill16<DO>(out, VecSel<true>::bias(m, m.nh), q);
         dense16<HT, DO, CGNN_EDGE_N16_GS>(out, oph, WSel<CGNN_BF16, true>::get(m, m.nh), lane);
         layer_norm16<DO>(out, VecSel<true>::gamma(m), VecSel<true>::beta(m), q);
+#ifdef CGNN_ABLATE_REPEAT
+        }
+#endif
         if (e_upd != nullptr) {
 #pragma unroll
             for (int o = 0; o < DO; ++o) *reinterpret_cast<f32x4*>(e_upd + tbase + n16_tile_offset(o)) = out[o];
         }
-        if (agg_out != nullptr && x_gather == nullptr) {   // message_source "edge": aggregate the update itself
+        if (AGG && agg_out != nullptr && x_gather == nullptr) {   // message_source "edge": aggregate the update itself
             const bool writer = (c & (seg_k - 1)) == 0 && e < num_edges;
 #pragma unroll
             for (int o = 0; o < DO; ++o) {
@@ -186,7 +206,7 @@ __global__ __launch_bounds__(CGNN_EDGE_N16_BLOCK) void edge_block_n16_kernel(
             if (residual) out[o] += ev[o];
             __builtin_nontemporal_store(out[o], reinterpret_cast<f32x4*>(e_out + tbase + n16_tile_offset(o)));
         }
-        if (agg_out != nullptr && x_gather != nullptr) {   // PyG default message: aggregate the sender node rows
+        if (AGG && agg_out != nullptr && x_gather != nullptr) {   // PyG default message: aggregate the sender node rows
             const bool writer = (c & (seg_k - 1)) == 0 && e < num_edges;
             const float* xr = x_gather + s * D + 4 * q;
 #pragma unroll
@@ -200,21 +220,42 @@ __global__ __launch_bounds__(CGNN_EDGE_N16_BLOCK) void edge_block_n16_kernel(
     }
 }
 
-template <int HT, int DT>
-static int launch_edge_n16(const MlpDev& m, size_t lds, const __bf16* ps, const __bf16* pd, const int32_t* src,
-                           const int32_t* dst, int64_t num_edges, const float* e_in, float* e_out, float* e_upd,
-                           int residual, const float* x_gather, float* agg_out, int seg_k, hipStream_t st) {
-    auto kern = edge_block_n16_kernel<HT, DT>;
+template <int HT, int DT, int BLOCK, bool AGG>
+static int launch_edge_n16_as(const MlpDev& m, size_t lds, const __bf16* ps, const __bf16* pd, const int32_t* src,
+                              const int32_t* dst, int64_t num_edges, const float* e_in, float* e_out, float* e_upd,
+                              int residual, const float* x_gather, float* agg_out, int seg_k, hipStream_t st) {
+    auto kern = edge_block_n16_kernel<HT, DT, BLOCK, AGG>;
     if (lds > 48 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                            "hipFuncSetAttribute(edge_block_n16)");
         if (rc != CGNN_OK) return rc;
     }
-    const int grid = grid_for_tiles((num_edges + 15) / 16, 1, CGNN_EDGE_N16_BLOCK / 64);
-    kern<<<grid, CGNN_EDGE_N16_BLOCK, lds, st>>>(m, ps, pd, src, dst, num_edges, e_in, e_out, e_upd, residual, x_gather,
-                                                 agg_out, seg_k);
+    const int grid = grid_for_tiles((num_edges + 15) / 16, 1, BLOCK / 64);
+    kern<<<grid, BLOCK, lds, st>>>(m, ps, pd, src, dst, num_edges, e_in, e_out, e_upd, residual, x_gather, agg_out,
+                                   seg_k);
     return check_hip(hipGetLastError(), "cgnn_edge_block(n16) launch");
+}
+
+// The weights occupy most of the LDS, so one workgroup runs per CU and its size sets the occupancy: 512 threads
+// (two waves per SIMD, 256 registers each) for the variant that also reduces the aggregate, 1024 threads (four waves
+// per SIMD, 128 registers) for the plain edge update.  CGNN_EDGE_N16_THREADS overrides (developer A/B).
+template <int HT, int DT>
+static int launch_edge_n16(const MlpDev& m, size_t lds, const __bf16* ps, const __bf16* pd, const int32_t* src,
+                           const int32_t* dst, int64_t num_edges, const float* e_in, float* e_out, float* e_upd,
+                           int residual, const float* x_gather, float* agg_out, int seg_k, hipStream_t st) {
+    static const int forced = [] {
+        const char* v = getenv("CGNN_EDGE_N16_THREADS");
+        return v ? atoi(v) : 0;
+    }();
+    if (agg_out != nullptr)
+        return launch_edge_n16_as<HT, DT, 512, true>(m, lds, ps, pd, src, dst, num_edges, e_in, e_out, e_upd, residual,
+                                                     x_gather, agg_out, seg_k, st);
+    if (forced == 512)
+        return launch_edge_n16_as<HT, DT, 512, false>(m, lds, ps, pd, src, dst, num_edges, e_in, e_out, e_upd, residual,
+                                                      x_gather, agg_out, seg_k, st);
+    return launch_edge_n16_as<HT, DT, 1024, false>(m, lds, ps, pd, src, dst, num_edges, e_in, e_out, e_upd, residual,
+                                                   x_gather, agg_out, seg_k, st);
 }
 
 // Edge encoder in the N16 layout (reference graph_network.py:57: MLP + LayerNorm on the 4 edge features): narrow

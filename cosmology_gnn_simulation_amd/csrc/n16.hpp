@@ -20,29 +20,41 @@ namespace cgnn {
 typedef const __attribute__((address_space(3))) f32x4* LdsVec4Ptr;
 
 // out[O] += W[16 O .. 16 O + 15, :] . in    fragment m = O * KS + s at wp[m * 64 + lane]
+// Issue order: blocks of OB = 4 output tiles, k-step by k-step, so that consecutive MFMAs write different
+// accumulators and an accumulator recurs only every fourth MFMA (a chain of back-to-back MFMAs on one accumulator
+// exposes the instruction's latency, about twice its issue time for 16x16x32).
 template <int KS, int OT, int GSMAX = 4>
 __device__ __forceinline__ void dense16(f32x4 (&out)[OT], const bf16x8 (&in)[KS], const LdsW& wp, int lane) {
     constexpr int M = OT * KS;
-    constexpr int GS = (M < GSMAX) ? M : GSMAX;
+    constexpr int OB = (OT % 4 == 0) ? 4 : ((OT % 2 == 0) ? 2 : 1);
+    constexpr int GS = (OB < GSMAX && M % GSMAX == 0 && OB == 4) ? GSMAX : OB;   // one (block, k-step) per group
     constexpr int NG = M / GS;
-    static_assert(M % GS == 0, "group size must divide the MFMA count");
+    static_assert(M % GS == 0 && GS % OB == 0, "group size must divide the MFMA count");
+    // issue index t -> (o, s): t = (ob * KS + s) * OB + oo
+#define CGNN_D16_O(t) (((t) / (KS * OB)) * OB + (t) % OB)
+#define CGNN_D16_S(t) (((t) / OB) % KS)
     bf16x8 buf[2][GS];
 #pragma unroll
-    for (int j = 0; j < GS; ++j) buf[0][j] = wp.fetch(j, lane);
+    for (int j = 0; j < GS; ++j) buf[0][j] = wp.fetch(CGNN_D16_O(j) * KS + CGNN_D16_S(j), lane);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         if (g + 1 < NG) {
 #pragma unroll
-            for (int j = 0; j < GS; ++j) buf[(g + 1) & 1][j] = wp.fetch((g + 1) * GS + j, lane);
+            for (int j = 0; j < GS; ++j) {
+                const int t = (g + 1) * GS + j;
+                buf[(g + 1) & 1][j] = wp.fetch(CGNN_D16_O(t) * KS + CGNN_D16_S(t), lane);
+            }
         }
 #pragma unroll
         for (int j = 0; j < GS; ++j) {
-            const int mm = g * GS + j;
-            const int o = mm / KS, s = mm % KS;
-            out[o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(buf[g & 1][j], in[s], out[o], 0, 0, 0);
+            const int t = g * GS + j;
+            out[CGNN_D16_O(t)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(buf[g & 1][j], in[CGNN_D16_S(t)],
+                                                                         out[CGNN_D16_O(t)], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+#undef CGNN_D16_O
+#undef CGNN_D16_S
 }
 
 // fragments [M0, M1) only, read from a source holding exactly that range
@@ -71,15 +83,35 @@ __device__ __forceinline__ void dense16_part(f32x4 (&out)[OT], const bf16x8 (&in
     }
 }
 
+// ReLU on packed bf16: as 16-bit integers the negative values (sign bit set, -0 included) are the negative integers,
+// so one v_pk_max_i16 per register does two values (the f32 form costs one v_max_f32 per value before the pack).
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 relu_bf16(bf16x8 v) {
+    const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, v), z));
+}
+
+// two f32 -> one register of two bf16 (a single v_cvt_pk_bf16_f32; element-wise conversions made hipcc convert each
+// value alone and merge the halves with v_perm_b32)
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
 template <bool RELU, int KS>
 __device__ __forceinline__ void operand16(bf16x8 (&op)[KS], const f32x4 (&acc)[2 * KS]) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float x = acc[2 * s + (j >> 2)][j & 3];
-            op[s][j] = (__bf16)(RELU ? fmaxf(x, 0.f) : x);
-        }
+    for (int s = 0; s < KS; ++s) {
+        u32x4 v;
+        v[0] = pack_bf16(acc[2 * s][0], acc[2 * s][1]);
+        v[1] = pack_bf16(acc[2 * s][2], acc[2 * s][3]);
+        v[2] = pack_bf16(acc[2 * s + 1][0], acc[2 * s + 1][1]);
+        v[3] = pack_bf16(acc[2 * s + 1][2], acc[2 * s + 1][3]);
+        const bf16x8 b = __builtin_bit_cast(bf16x8, v);
+        op[s] = RELU ? relu_bf16(b) : b;
+    }
 }
 
 template <int OT>
@@ -88,42 +120,55 @@ __device__ __forceinline__ void fill16(f32x4 (&acc)[OT], LdsVecPtr b, int q) {
     for (int o = 0; o < OT; ++o) acc[o] = *(LdsVec4Ptr)(b + 16 * o + 4 * q);
 }
 
-// P rows for the N16 kernel: bf16, H values per row stored [q][O][i]; lane (c, q) reads H/4 contiguous values.
-template <int OT, bool ADD>
-__device__ __forceinline__ void load_p16(f32x4 (&acc)[OT], const __bf16* __restrict__ base, int64_t row, int q) {
-    const bf16x8* p = reinterpret_cast<const bf16x8*>(base + row * (16 * OT) + q * (4 * OT));
+// P rows for the N16 kernel (CGNN_P_BF16_S16): bf16, stored in B-operand order -- for k-step s (features 32 s .. 32 s
+// + 31) lane (c, q) owns the 16 bytes at (4 s + q) * 16, elements j = features phi(s, q, j).  The rows then enter the
+// first layer's accumulators through the matrix pipe (two MFMAs per 16-feature tile against constant 0/1 selector
+// fragments) instead of 2 x 32 bf16 -> f32 unpacks and 32 adds per lane on the vector pipe, which was the busier one.
+template <int KS>
+__device__ __forceinline__ void load_p16_operand(bf16x8 (&op)[KS], const __bf16* __restrict__ base, int64_t row, int q) {
+    const bf16x8* p = reinterpret_cast<const bf16x8*>(base + row * (32 * KS)) + q;
 #pragma unroll
-    for (int j = 0; j < OT / 2; ++j) {
-        const bf16x8 v = p[j];
+    for (int s = 0; s < KS; ++s) op[s] = p[4 * s];
+}
+// A fragment that copies the 16 features {phi(s, q', j') : j' >> 2 == sub} of a k-step to the 16 rows of a C tile:
+// row m = 4 q' + (j' & 3)  <-  k = 8 q' + j' = 8 (m >> 2) + 4 sub + (m & 3); lane (m, q) holds A[m][8 q + j].
+__device__ __forceinline__ bf16x8 p16_selector(int lane, int sub) {
+    const int m = lane & 15, q = lane >> 4;
+    bf16x8 a;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            if (ADD)
-                acc[2 * j + (c >> 2)][c & 3] += (float)v[c];
-            else
-                acc[2 * j + (c >> 2)][c & 3] = (float)v[c];
-        }
-    }
+    for (int j = 0; j < 8; ++j) a[j] = (__bf16)((q == (m >> 2) && j == 4 * sub + (m & 3)) ? 1.0f : 0.0f);
+    return a;
+}
+template <int KS>
+__device__ __forceinline__ void p16_accumulate(f32x4 (&acc)[2 * KS], const bf16x8 (&ps)[KS], const bf16x8 (&pd)[KS],
+                                               bf16x8 sel0, bf16x8 sel1) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 2 * KS; ++o)
+        acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((o & 1) ? sel1 : sel0, ps[o >> 1], zero, 0, 0, 0);
+#pragma unroll
+    for (int o = 0; o < 2 * KS; ++o)
+        acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((o & 1) ? sel1 : sel0, pd[o >> 1], acc[o], 0, 0, 0);
 }
 
-// LayerNorm over the 16 OT features of each edge; an edge's features live on lanes c, c+16, c+32, c+48.
+// LayerNorm over the 16 OT features of each edge; an edge's features live on lanes c, c+16, c+32, c+48.  Two passes
+// (mean, then centred squares) on whole f32x4 registers so that hipcc emits packed f32 instructions.
 template <int OT>
 __device__ __forceinline__ void layer_norm16(f32x4 (&a)[OT], LdsVecPtr gamma, LdsVecPtr beta, int q) {
-    float s = 0.f;
+    f32x4 s4 = a[0];
 #pragma unroll
-    for (int o = 0; o < OT; ++o)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s += a[o][i];
+    for (int o = 1; o < OT; ++o) s4 += a[o];
+    float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
     const float mean = s * (1.0f / (16 * OT));
-    float v = 0.f;
+    f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int o = 0; o < OT; ++o)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float d = a[o][i] - mean;
-            v += d * d;
-        }
+    for (int o = 0; o < OT; ++o) {
+        a[o] -= mean;
+        v4 += a[o] * a[o];
+    }
+    float v = (v4[0] + v4[1]) + (v4[2] + v4[3]);
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
     const float rstd = 1.0f / sqrtf(v * (1.0f / (16 * OT)) + 1e-5f);
@@ -131,8 +176,7 @@ __device__ __forceinline__ void layer_norm16(f32x4 (&a)[OT], LdsVecPtr gamma, Ld
     for (int o = 0; o < OT; ++o) {
         const f32x4 gm = *(LdsVec4Ptr)(gamma + 16 * o + 4 * q);
         const f32x4 bt = *(LdsVec4Ptr)(beta + 16 * o + 4 * q);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[o][i] = (a[o][i] - mean) * rstd * gm[i] + bt[i];
+        a[o] = a[o] * (gm * rstd) + bt;
     }
 }
 
@@ -262,19 +306,20 @@ __device__ __forceinline__ void layer_norm16_global(f32x4 (&a)[OT], const float*
     }
 }
 
-// P rows written from the N16 layout.  S16: lane (c, q) owns the contiguous run [q][O][i].  S32: feature
+// P rows written from the N16 layout.  S16: B-operand order, the pair of tiles (2 s, 2 s + 1) of lane (c, q) is the
+// 16-byte element (4 s + q) of the row (see load_p16_operand).  S32: feature
 // 16 O + 4 q + i = 32 t + 8 g + 4 h + i with t = O >> 1, g = 2 (O & 1) + (q >> 1), h = q & 1.
 template <int PFMT, int OT>
 __device__ __forceinline__ void store_p16(const f32x4 (&acc)[OT], __bf16* __restrict__ base, int64_t row, int q) {
     __bf16* rp = base + row * (16 * OT);
     if (PFMT == CGNN_P_BF16_S16) {
-        bf16x8* p = reinterpret_cast<bf16x8*>(rp + q * (4 * OT));
+        bf16x8* p = reinterpret_cast<bf16x8*>(rp) + q;
 #pragma unroll
         for (int j = 0; j < OT / 2; ++j) {
             bf16x8 v;
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[c] = (__bf16)acc[2 * j + (c >> 2)][c & 3];
-            p[j] = v;
+            p[4 * j] = v;
         }
     } else {
 #pragma unroll

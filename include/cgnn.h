@@ -61,7 +61,8 @@ typedef enum {
  * Feature f of a row of H values:
  *   CGNN_P_F32       float32, position f                                  (mlp precision CGNN_F32)
  *   CGNN_P_BF16_S32  bf16, f = 32t+8g+4h+c at h*(H/2) + (4t+g)*4 + c      (mlp precision CGNN_BF16)
- *   CGNN_P_BF16_S16  bf16, f = 16O+4q+i    at q*(H/4) + 4*O + i           (mlp precision CGNN_BF16_N16)
+ *   CGNN_P_BF16_S16  bf16, f = 16O+4q+i    at (4*(O/2) + q)*8 + 4*(O%2) + i   (mlp precision CGNN_BF16_N16: the
+ *                    16-edge kernel's MFMA B-operand order, so the rows enter the accumulators through the matrix pipe)
  * i.e. each lane of the consuming kernel reads one contiguous run. */
 typedef enum { CGNN_P_F32 = 0, CGNN_P_BF16_S32 = 1, CGNN_P_BF16_S16 = 2 } cgnn_ptable;
 
