@@ -50,6 +50,8 @@ def parse_args():
     p.add_argument("--node-precision", default="fp32x3", choices=["bf16", "fp32", "fp32x3"],
                    help="fp32x3 = f32 emulated with three bf16 terms on the bf16 matrix cores (holds the 1e-5 gate)")
     p.add_argument("--message-source", default="x_j", choices=["x_j", "edge"])
+    p.add_argument("--no-fuse-rounds", action="store_true",
+                   help="x_j mode: one edge-kernel launch per round instead of cgnn_edge_stream (all rounds in one launch)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-particles", type=int, default=16384, help="bounded CPU-baseline sample size")
     p.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (box share)")
@@ -130,6 +132,7 @@ def main():
     model = model.to(dev).eval()
     model.edge_precision, model.node_precision = args.edge_precision, args.node_precision
     model.message_source = args.message_source
+    model.fuse_rounds = not args.no_fuse_rounds
 
     dist_ctx = None
     if world > 1:
@@ -220,38 +223,58 @@ def main():
     value = e_total * L / (elapsed / args.steps)
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (the fused edge block), from HIP events in the timed region ----
-        if "edge_block" not in per_op:      # HIP-graph replay: launches are inside the graph, no per-op events
-            per_op = {"edge_block": (1, float("nan"))}
-        calls, total_ms = per_op["edge_block"]
-        edge_ms = total_ms / calls
-        sz_w = 2 if args.edge_precision == "bf16" else 4
-        # algorithmic HBM bytes per launch: f32 edge latents read once + written once, src/dst indices, and the
-        # per-node Ps/Pd tables (bf16 in bf16 mode) read once (gather re-reads are cache traffic, not algorithmic)
-        alg_bytes = 2 * e_local * d * 4 + 2 * e_local * 4 + 2 * n_local * h * (2 if args.edge_precision == "bf16" else 4)
-        achieved = alg_bytes / (edge_ms * 1e-3) / 1e9
+        # ---- roofline of the dominant kernel, from HIP events on the launch stream inside the timed region ----
+        sz_p = 2 if args.edge_precision == "bf16" else 4
+        mfma_peak = MFMA_BF16_PEAK_TFLOPS if args.edge_precision == "bf16" else MFMA_F32_PEAK_TFLOPS
+        # per round: useful MFMA flops of the edge model as executed (first Linear split by columns: only the We block
+        # runs per edge) and as the reference formulates it (3D-wide first Linear per edge)
         flops_exec = 2.0 * e_local * (d * h + (args.hidden_layers - 1) * h * h + h * d)
         flops_alg = 2.0 * e_local * (3 * d * h + (args.hidden_layers - 1) * h * h + h * d)
-        mfma_peak = MFMA_BF16_PEAK_TFLOPS if args.edge_precision == "bf16" else MFMA_F32_PEAK_TFLOPS
-        n16 = args.edge_precision == "bf16" and d <= 128 and h <= 128
-        edge_kernel_name = (f"cgnn::edge_block_n16_kernel<{h // 32},{d // 32}>" if n16 else
-                            f"cgnn::edge_block_kernel<{args.edge_precision},{h // 32},{d // 32}>")
-        traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        traffic_db = {}
         if os.path.isfile(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"edge_block:{n_local}:{k}:{d}:{args.edge_precision}")
+                traffic_db = json.load(open(tpath))
             except Exception:
-                traffic = None
-        roofline = {"kernel": edge_kernel_name, "bound": "hbm", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "avg_launch_ms": round(edge_ms, 4), "launches": calls,
-                    "algorithmic_bytes_per_launch": alg_bytes,
-                    "mfma": {"executed_tflops": round(flops_exec / (edge_ms * 1e-3) / 1e12, 1),
-                             "algorithmic_tflops": round(flops_alg / (edge_ms * 1e-3) / 1e12, 1),
-                             "peak_tflops": mfma_peak,
-                             "frac_executed": round(flops_exec / (edge_ms * 1e-3) / 1e12 / mfma_peak, 4),
-                             "frac_algorithmic": round(flops_alg / (edge_ms * 1e-3) / 1e12 / mfma_peak, 4)}}
+                traffic_db = {}
+        if "edge_stream" in per_op:
+            # all L rounds in one launch (reference data flow): the edge latents cross HBM once, the kernel is bound by
+            # the matrix pipe.  Algorithmic bytes: e read + written once, src/dst, and every round's Ps/Pd tables once.
+            calls, total_ms = per_op["edge_stream"]
+            edge_ms = total_ms / calls
+            alg_bytes = 2 * e_local * d * 4 + 2 * e_local * 4 + L * 2 * n_local * h * sz_p
+            tf = L * flops_exec / (edge_ms * 1e-3) / 1e12
+            roofline = {"kernel": f"cgnn::edge_stream_n16_kernel<{h // 32},{d // 32}>", "bound": "mfma",
+                        "achieved": round(tf, 1), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(tf / mfma_peak, 4),
+                        "traffic": traffic_db.get(f"edge_stream:{n_local}:{k}:{d}:{L}"),
+                        "avg_launch_ms": round(edge_ms, 4), "launches": calls,
+                        "algorithmic_flops_per_launch": L * flops_exec,
+                        "reference_formulation_tflops": round(L * flops_alg / (edge_ms * 1e-3) / 1e12, 1),
+                        "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
+                                "achieved_GBps": round(alg_bytes / (edge_ms * 1e-3) / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
+                                "frac": round(alg_bytes / (edge_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+        else:
+            if "edge_block" not in per_op:      # HIP-graph replay: launches are inside the graph, no per-op events
+                per_op = dict(per_op, edge_block=(1, float("nan")))
+            calls, total_ms = per_op["edge_block"]
+            edge_ms = total_ms / calls
+            # algorithmic HBM bytes per launch: f32 edge latents read once + written once, src/dst indices, and the
+            # per-node Ps/Pd tables read once (gather re-reads are cache traffic, not algorithmic)
+            alg_bytes = 2 * e_local * d * 4 + 2 * e_local * 4 + 2 * n_local * h * sz_p
+            achieved = alg_bytes / (edge_ms * 1e-3) / 1e9
+            n16 = args.edge_precision == "bf16" and d <= 128 and h <= 128
+            edge_kernel_name = (f"cgnn::edge_block_n16_kernel<{h // 32},{d // 32}>" if n16 else
+                                f"cgnn::edge_block_kernel<{args.edge_precision},{h // 32},{d // 32}>")
+            roofline = {"kernel": edge_kernel_name, "bound": "hbm", "achieved": round(achieved, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": traffic_db.get(f"edge_block:{n_local}:{k}:{d}:{args.edge_precision}"),
+                        "avg_launch_ms": round(edge_ms, 4), "launches": calls,
+                        "algorithmic_bytes_per_launch": alg_bytes,
+                        "mfma": {"executed_tflops": round(flops_exec / (edge_ms * 1e-3) / 1e12, 1),
+                                 "algorithmic_tflops": round(flops_alg / (edge_ms * 1e-3) / 1e12, 1),
+                                 "peak_tflops": mfma_peak,
+                                 "frac_executed": round(flops_exec / (edge_ms * 1e-3) / 1e12 / mfma_peak, 4),
+                                 "frac_algorithmic": round(flops_alg / (edge_ms * 1e-3) / 1e12 / mfma_peak, 4)}}
         kernels = {name: {"calls": c, "avg_ms": round(ms / c, 4)} for name, (c, ms) in sorted(per_op.items())}
         if "aggregate" in per_op:
             c, ms = per_op["aggregate"]

@@ -1,0 +1,343 @@
+// cgnn_edge_stream: all message-passing rounds of the EDGE stream in one launch (reference graph_network.py:89-90,182
+// for round = 0 .. L-1), for the reference's actual data flow.
+//
+// Under the reference's aggregation (PyG's default message: sender NODE latents) the node stream never
+// reads the edge stream, so the per-node halves Ps_r / Pd_r of every round's first edge Linear are known before any
+// edge is touched.  An edge's latent tile can then stay in registers through all L updates
+//     e <- e + LN_r(MLP_r(Ps_r[src] + Pd_r[dst] + We_r e))          r = 0 .. L-1
+// and the E x D f32 stream crosses HBM once instead of L times (cfg3: 16 GB instead of 164 GB).  What no longer
+// fits is the weights: one round's three 128x128 bf16 layers fill the LDS, so the layers of all rounds cycle through
+// a three-slot LDS ring, copied by LDS-DMA two layers ahead of their use; the eight waves of a workgroup meet at one
+// barrier per layer.  Arithmetic (MFMA shapes, operand order, f32 LayerNorm and residual) is that of
+// edge_block_n16_kernel, so the result is bit-identical to L per-round launches.
+#include <stdlib.h>
+#include <string.h>
+
+#include "n16.hpp"
+
+namespace cgnn {
+
+#define CGNN_STREAM_BLOCK 512
+#define CGNN_STREAM_WAVES (CGNN_STREAM_BLOCK / 64)
+#define CGNN_STREAM_SLOTS 3
+#define CGNN_STREAM_MAX_CHUNKS 64
+#define CGNN_STREAM_MAX_ROUNDS 32
+
+struct StreamArgs {
+    const char* w[CGNN_STREAM_MAX_CHUNKS];       // packed CGNN_BF16_N16 layers in consumption order (round-major)
+    const float* bias[CGNN_STREAM_MAX_CHUNKS];   // bias of the same layer (entry of a round's layer 0 unused: it is in Pd)
+    const float* gamma[CGNN_STREAM_MAX_ROUNDS];
+    const float* beta[CGNN_STREAM_MAX_ROUNDS];
+    uint32_t chunk_bytes[CGNN_STREAM_MAX_CHUNKS];
+    int32_t rounds, nh;
+};
+
+typedef __attribute__((address_space(3))) void* LdsVoidPtrS;
+typedef const __attribute__((address_space(1))) void* GlobalVoidPtrS;
+
+#define CGNN_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+// The ring.  Every wave copies its share (1-KiB pieces wave, wave + 8, ...) of a layer into a slot with LDS-DMA.
+// The wave's vector-memory operations retire in issue order, so "the pieces of layer c have landed" is a counted
+// s_waitcnt: at most as many operations outstanding as this wave has issued since those pieces.  after[] tracks that
+// number for the two layers in flight (wave-uniform scalars); other loads and stores of the kernel report themselves
+// with note().
+template <uint32_t SLOT_BYTES>
+struct LayerRing {
+    const StreamArgs& a;
+    int wave, lane;
+    int count;           // layers per tile = rounds * (nh + 1)
+    int chunk;           // layer the next acquire() returns
+    int slot;            // its slot
+    int left;            // acquires still to come (over all tiles of this workgroup)
+    int after0, after1;  // operations issued after the pieces of `chunk` / of the layer after it
+    __device__ __forceinline__ LayerRing(const StreamArgs& aa, int w, int l, int steps)
+        : a(aa), wave(w), lane(l), count(aa.rounds * (aa.nh + 1)), chunk(0), slot(0), left(steps), after0(0), after1(0) {}
+
+    __device__ __forceinline__ int issue(int c, int s) const {
+        asm volatile("" ::: "memory");
+        const char* src = a.w[c];
+        const uint32_t nb = a.chunk_bytes[c];
+        char* dst = cgnn_smem + s * SLOT_BYTES;
+        int n = 0;
+        for (uint32_t off = wave * 1024u; off < nb; off += CGNN_STREAM_WAVES * 1024u) {
+            __builtin_amdgcn_global_load_lds((GlobalVoidPtrS)(src + off + lane * 16), (LdsVoidPtrS)(dst + off), 16, 0, 0);
+            ++n;
+        }
+        asm volatile("" ::: "memory");
+        return n;
+    }
+    __device__ __forceinline__ void note(int ops) {
+        after0 += ops;
+        after1 += ops;
+    }
+    __device__ __forceinline__ void prime() {    // layers 0 and 1 of the first tile
+        const int n0 = issue(0, 0);
+        (void)n0;
+        after0 = 0;
+        if (left > 1) {
+            const int n1 = issue(count > 1 ? 1 : 0, 1);
+            after0 = n1;
+        }
+        after1 = 0;
+    }
+    // Layer `chunk` readable by every wave; returns its LDS image.  start_next() then starts the copy of the layer two
+    // ahead (into the slot everybody has just left).  They are separate so that a caller can first consume registers
+    // whose loads the compiler guards with a full vmcnt(0) -- it cannot count across the loop's back edge -- while
+    // only old operations are outstanding.
+    __device__ __forceinline__ LdsW wait_ready() {
+        const int n = __builtin_amdgcn_readfirstlane(after0);
+        if (n >= 12)
+            CGNN_VMCNT(12);
+        else if (n >= 4)
+            CGNN_VMCNT(4);
+        else if (n >= 1)
+            CGNN_VMCNT(1);
+        else
+            CGNN_VMCNT(0);
+        __builtin_amdgcn_s_barrier();   // everybody's pieces have landed, and everybody is done with the previous layer's slot
+        asm volatile("" ::: "memory");
+        return LdsW((LdsWeightPtr)(cgnn_smem + slot * SLOT_BYTES));
+    }
+    __device__ __forceinline__ void start_next() {
+        --left;
+        int c2 = chunk + 2;
+        if (c2 >= count) c2 -= count;
+        if (c2 >= count) c2 -= count;          // count == 1
+        const int s2 = slot == 0 ? 2 : slot - 1;   // (slot + 2) % 3
+        after0 = after1;
+        after1 = 0;
+        if (left > 1) after0 += issue(c2, s2);
+        chunk = chunk + 1 == count ? 0 : chunk + 1;
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    __device__ __forceinline__ LdsW acquire() {
+        const LdsW w = wait_ready();
+        start_next();
+        return w;
+    }
+};
+
+template <int HT, int DT>
+__global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
+    StreamArgs a, const __bf16* __restrict__ ps_all, const __bf16* __restrict__ pd_all, int64_t round_stride,
+    const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t num_edges, const float* e_in, float* e_out) {
+    constexpr int D = 32 * DT, H = 32 * HT, DO = 2 * DT, HO = 2 * HT;
+    constexpr int W = H > D ? H : D;
+    constexpr uint32_t SLOT = 2u * (uint32_t)(H * (H > D ? H : D));
+    const int L = a.rounds, nh = a.nh, NV = nh + 2;      // vectors per round: biases of layers 1..nh, gamma, beta
+    float* vecs = reinterpret_cast<float*>(cgnn_smem + CGNN_STREAM_SLOTS * SLOT);
+    for (int idx = threadIdx.x; idx < L * NV * W; idx += blockDim.x) {
+        const int r = idx / (NV * W), v = (idx / W) % NV, i = idx % W;
+        const float* p = v < nh ? a.bias[r * (nh + 1) + v + 1] : (v == nh ? a.gamma[r] : a.beta[r]);
+        const int dim = v < nh - 1 ? H : D;
+        vecs[idx] = (p != nullptr && i < dim) ? p[i] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t tiles = (num_edges + 15) / 16;
+    const TileRange tr = tile_range(tiles);
+    // every wave of the workgroup runs the same number of tile iterations (they share the ring's barriers): the count
+    // of wave 0; a wave whose last tile falls off the range recomputes its previous tile and skips the store
+    const int64_t first0 = tr.first - wave;
+    // (the 64-bit division runs on the vector unit: tell the compiler its result is wave-uniform)
+    const int iters = __builtin_amdgcn_readfirstlane(
+        first0 < tr.end ? (int)((tr.end - first0 + tr.stride - 1) / tr.stride) : 0);
+    if (iters == 0) return;
+    LayerRing<SLOT> ring(a, wave, lane, iters * L * (nh + 1));
+    ring.prime();
+    const bf16x8 sel0 = p16_selector(lane, 0), sel1 = p16_selector(lane, 1);
+    const LdsVecPtr vbase = (LdsVecPtr)(cgnn_smem + CGNN_STREAM_SLOTS * SLOT);
+
+    int64_t tile = tr.first < tr.end ? tr.first : tr.end - 1;
+    bool valid = tr.first < tr.end;
+    int64_t tbase = (tile >> 1) * (32 * D) + n16_lane_offset(c, q, (int)(tile & 1));
+    int64_t s, d;
+    {
+        const int64_t e = tile * 16 + c;
+        const int64_t ec = e < num_edges ? e : num_edges - 1;
+        s = src[ec];
+        d = dst[ec];
+    }
+    f32x4 ev[DO];
+#pragma unroll
+    for (int o = 0; o < DO; ++o)
+        ev[o] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(e_in + tbase + n16_tile_offset(o)));
+    bf16x8 pso[HT], pdo[HT];
+    load_p16_operand<HT>(pso, ps_all, s, q);
+    load_p16_operand<HT>(pdo, pd_all, d, q);
+    ring.note(2 + DO + 2 * HT);
+
+    for (int it = 0; it < iters; ++it) {
+        const bool more = it + 1 < iters;
+        int64_t tile_n = tile + tr.stride;
+        const bool valid_n = tile_n < tr.end;
+        if (!valid_n) tile_n = tile;
+        const int64_t tbase_n = (tile_n >> 1) * (32 * D) + n16_lane_offset(c, q, (int)(tile_n & 1));
+        int32_t s_n = (int32_t)s, d_n = (int32_t)d;     // widened only where they are used, a tile later
+        f32x4 ev_n[DO];
+        for (int r = 0; r < L; ++r) {
+            const LdsVecPtr vr = vbase + r * NV * W;
+            bf16x8 oph[HT];
+            {
+                const LdsW w0 = ring.wait_ready();
+                f32x4 acc[HO];
+                p16_accumulate<HT>(acc, pso, pdo, sel0, sel1);
+                if (r == 0 && more) {      // the next tile's edge list entries, a whole tile ahead of their use
+                    const int64_t e = tile_n * 16 + c;
+                    const int64_t ec = e < num_edges ? e : num_edges - 1;
+                    s_n = src[ec];
+                    d_n = dst[ec];
+                    ring.note(2);
+                }
+                // the P registers are free again: fetch the rows of the next round (or of the next tile's round 0)
+                if (r + 1 < L) {
+                    load_p16_operand<HT>(pso, ps_all + (r + 1) * round_stride, s, q);
+                    load_p16_operand<HT>(pdo, pd_all + (r + 1) * round_stride, d, q);
+                    ring.note(2 * HT);
+                } else if (more) {
+                    load_p16_operand<HT>(pso, ps_all, s_n, q);
+                    load_p16_operand<HT>(pdo, pd_all, d_n, q);
+#pragma unroll
+                    for (int o = 0; o < DO; ++o)
+                        ev_n[o] = __builtin_nontemporal_load(
+                            reinterpret_cast<const f32x4*>(e_in + tbase_n + n16_tile_offset(o)));
+                    ring.note(2 * HT + DO);
+                }
+                ring.start_next();     // after the prefetches: the waits the compiler puts before them see only old loads
+                bf16x8 op[DT];
+                operand16<false, DT>(op, ev);
+                dense16<DT, HO, 4>(acc, op, w0, lane);
+                operand16<true, HT>(oph, acc);
+            }
+            for (int l = 1; l < nh; ++l) {
+                const LdsW wl = ring.acquire();
+                f32x4 acc[HO];
+                fill16<HO>(acc, vr + (l - 1) * W, q);
+                dense16<HT, HO, 4>(acc, oph, wl, lane);
+                operand16<true, HT>(oph, acc);
+            }
+            const LdsW wo = ring.acquire();
+            f32x4 out[DO];
+            fill16<DO>(out, vr + (nh - 1) * W, q);
+            dense16<HT, DO, 4>(out, oph, wo, lane);
+            layer_norm16<DO>(out, vr + nh * W, vr + (nh + 1) * W, q);
+#pragma unroll
+            for (int o = 0; o < DO; ++o) ev[o] += out[o];
+        }
+        if (valid) {
+#pragma unroll
+            for (int o = 0; o < DO; ++o)
+                __builtin_nontemporal_store(ev[o], reinterpret_cast<f32x4*>(e_out + tbase + n16_tile_offset(o)));
+            ring.note(DO);
+        }
+        if (more) {
+#pragma unroll
+            for (int o = 0; o < DO; ++o) ev[o] = ev_n[o];
+            tile = tile_n;
+            tbase = tbase_n;
+            valid = valid_n;
+            s = s_n;
+            d = d_n;
+        }
+    }
+}
+
+template <int HT, int DT>
+static int launch_stream(const StreamArgs& a, size_t lds, const __bf16* ps, const __bf16* pd, int64_t round_stride,
+                         const int32_t* src, const int32_t* dst, int64_t num_edges, const float* e_in, float* e_out,
+                         hipStream_t st) {
+    auto kern = edge_stream_n16_kernel<HT, DT>;
+    if (lds > 48 * 1024) {
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                           "hipFuncSetAttribute(edge_stream)");
+        if (rc != CGNN_OK) return rc;
+    }
+    const int grid = grid_for_tiles((num_edges + 15) / 16, 1, CGNN_STREAM_WAVES);
+    kern<<<grid, CGNN_STREAM_BLOCK, lds, st>>>(a, ps, pd, round_stride, src, dst, num_edges, e_in, e_out);
+    return check_hip(hipGetLastError(), "cgnn_edge_stream launch");
+}
+
+}  // namespace cgnn
+
+using namespace cgnn;
+
+extern "C" int cgnn_edge_stream(const cgnn_mlp* rounds, int32_t num_rounds, const void* ps_all, const void* pd_all,
+                                int64_t round_stride, const int32_t* src, const int32_t* dst, int64_t num_edges,
+                                const float* e_in, float* e_out, int32_t latent, void* stream) {
+    if (!rounds || num_rounds < 1 || !ps_all || !pd_all || !src || !dst || !e_in || !e_out || num_edges < 0 ||
+        latent <= 0 || round_stride < 0) {
+        set_error("cgnn_edge_stream: invalid argument");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if (num_rounds > CGNN_STREAM_MAX_ROUNDS) {
+        set_error("cgnn_edge_stream: %d rounds, at most %d", num_rounds, CGNN_STREAM_MAX_ROUNDS);
+        return CGNN_ERR_UNSUPPORTED;
+    }
+    StreamArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rounds = num_rounds;
+    int hidden = 0, nh = 0;
+    for (int r = 0; r < num_rounds; ++r) {
+        MlpDev m;
+        int rc = make_mlp_dev(&rounds[r], &m, nullptr, "cgnn_edge_stream");
+        if (rc != CGNN_OK) return rc;
+        if (rounds[r].precision != CGNN_BF16_N16 || !m.gamma) {
+            set_error("cgnn_edge_stream: round %d needs CGNN_BF16_N16 weights and LayerNorm parameters", r);
+            return CGNN_ERR_UNSUPPORTED;
+        }
+        if (r == 0) {
+            hidden = m.out_dim[0];
+            nh = m.nh;
+            if ((int64_t)num_rounds * (nh + 1) > CGNN_STREAM_MAX_CHUNKS) {
+                set_error("cgnn_edge_stream: %d rounds x %d layers exceed %d ring entries", num_rounds, nh + 1,
+                          CGNN_STREAM_MAX_CHUNKS);
+                return CGNN_ERR_UNSUPPORTED;
+            }
+        }
+        if (m.nh != nh || m.in_dim[0] != latent || m.out_dim[0] != hidden || m.out_dim[nh] != latent ||
+            m.in_dim[nh] != hidden) {
+            set_error("cgnn_edge_stream: round %d does not have the shape of round 0 (latent %d, hidden %d, %d hidden "
+                      "layers)", r, latent, hidden, nh);
+            return CGNN_ERR_INVALID_ARG;
+        }
+        for (int l = 0; l <= nh; ++l) {
+            if (l >= 1 && l < nh && (m.in_dim[l] != hidden || m.out_dim[l] != hidden)) {
+                set_error("cgnn_edge_stream: round %d hidden layer %d has the wrong shape", r, l);
+                return CGNN_ERR_INVALID_ARG;
+            }
+            const int ci = r * (nh + 1) + l;
+            a.w[ci] = (const char*)m.w[l];
+            a.bias[ci] = m.b[l];
+            a.chunk_bytes[ci] = m.bytes[l];
+        }
+        a.gamma[r] = m.gamma;
+        a.beta[r] = m.beta;
+    }
+    a.nh = nh;
+    if (latent % 32 || hidden % 32) {
+        set_error("cgnn_edge_stream: latent %d / hidden %d must be multiples of 32", latent, hidden);
+        return CGNN_ERR_UNSUPPORTED;
+    }
+    if (num_edges == 0) return CGNN_OK;
+    const int HT = hidden / 32, DT = latent / 32;
+    const int wmax = hidden > latent ? hidden : latent;
+    const size_t slot = 2u * (size_t)hidden * wmax;
+    const size_t lds = CGNN_STREAM_SLOTS * slot + (size_t)num_rounds * (nh + 2) * wmax * 4;
+    if (lds > 160 * 1024) {
+        set_error("cgnn_edge_stream: needs %zu bytes of LDS (three %zu-byte layer slots + %d rounds of vectors)", lds, slot,
+                  num_rounds);
+        return CGNN_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+#define CGNN_STREAM(Hh, Dd)   \
+    if (HT == Hh && DT == Dd) \
+        return launch_stream<Hh, Dd>(a, lds, (const __bf16*)ps_all, (const __bf16*)pd_all, round_stride, src, dst, num_edges, e_in, e_out, st);
+    CGNN_STREAM(1, 1) CGNN_STREAM(2, 2) CGNN_STREAM(4, 4)
+#undef CGNN_STREAM
+    set_error("cgnn_edge_stream: no kernel for latent=%d hidden=%d (built for hidden == latent in {32,64,128})", latent,
+              hidden);
+    return CGNN_ERR_UNSUPPORTED;
+}

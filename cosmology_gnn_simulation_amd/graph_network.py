@@ -287,6 +287,29 @@ def _run_round(p: _PackedProcessor, x: torch.Tensor, e: torch.Tensor, src, dst, 
     return x_new, e_new, nxt is not None
 
 
+def _run_rounds_fused(rounds, x: torch.Tensor, e, src, dst, fixed_k: int, agg: Optional[torch.Tensor]):
+    """All residual rounds under the reference's data flow (aggregation of sender NODE latents): the node
+    stream does not read the edge stream, so it runs first and leaves every round's Ps / Pd tables behind (the node
+    kernel's epilogue writes round i+1's); then one launch applies all edge updates while each edge tile stays in
+    registers.  Same kernels' arithmetic as the round-by-round path: results are bit-identical."""
+    n, L = x.shape[0], len(rounds)
+    H = rounds[0].ws.out_dim
+    ps_all = torch.empty((L, n, H), dtype=torch.bfloat16, device=x.device)
+    pd_all = torch.empty((L, n, H), dtype=torch.bfloat16, device=x.device)
+    fmt = rounds[0].p_format
+    ops.project_nodes(rounds[0].ws, rounds[0].wd, x, ps_all[0], pd_all[0], fmt)
+    for i, p in enumerate(rounds):
+        agg = ops.aggregate(x, src, dst, n, fixed_k, src.numel(), agg)
+        nxt = None
+        if i + 1 < L:
+            q = rounds[i + 1]
+            fused_ok = p.node.precision == _lib.F32X3_N16 and q.ws_fused.precision == _lib.BF16_N16
+            nxt = (q.ws_fused if fused_ok else q.ws, q.wd_fused if fused_ok else q.wd, ps_all[i + 1], pd_all[i + 1], fmt)
+        x = ops.node_block(p.node, p.wx, p.wa, x, agg, x, True, nxt)
+    e = ops.edge_stream([p.edge for p in rounds], ps_all, pd_all, src, dst, e, e)
+    return x, e
+
+
 class InteractionNetwork(nn.Module):
     """One round of message passing without residuals (reference
     graph_network.py:67-101): edge update from (sender, receiver, edge), sum
@@ -365,6 +388,7 @@ class EncodeProcessDecode(nn.Module):
         self.node_precision = "fp32"
         self.edge_precision = "fp32"
         self.locality_sort = True     # run in the k-NN build's spatial order when the graph carries it
+        self.fuse_rounds = True       # x_j mode: all rounds of the edge stream in one launch (cgnn_edge_stream)
         self._packed = None
         self._train_packed = None
 
@@ -401,6 +425,19 @@ class EncodeProcessDecode(nn.Module):
         )
         self._packed = (key, packed)
         return packed
+
+    def _can_fuse_rounds(self, rounds, latent: int) -> bool:
+        """One launch for the whole edge stream (``cgnn_edge_stream``): only under the reference's own data flow
+        (``message_source="x_j"``: the node stream never reads the edge stream), with the 16-edge bf16 kernels."""
+        if not (self.fuse_rounds and self.message_source == "x_j" and rounds):
+            return False
+        nh = rounds[0].edge.num_hidden_layers
+        if len(rounds) > 32 or len(rounds) * (nh + 1) > 64 or latent not in (32, 64, 128):
+            return False
+        lds = 3 * 2 * latent * latent + len(rounds) * (nh + 2) * latent * 4
+        return lds <= 160 * 1024 and all(
+            p.edge.precision == _lib.BF16_N16 and p.p_format == _lib.P_BF16_S16 and p.edge.hidden == latent and
+            p.edge.num_hidden_layers == nh for p in rounds)
 
     # -- forward ---------------------------------------------------------------
     def forward(self, input_graph) -> dict:
@@ -494,6 +531,9 @@ class EncodeProcessDecode(nn.Module):
                 scratch = (ps, pd, agg, e_upd)
             projected = False
             rounds = P["rounds"]
+            if self._can_fuse_rounds(rounds, xl.shape[1]):
+                xl, el = _run_rounds_fused(rounds, xl, el, src, dst, fixed_k, agg)
+                rounds = []
             for i, p in enumerate(rounds):
                 # residual streams updated in place (reference graph_network.py:181-182); the node kernel also
                 # emits the next round's sender / receiver projections

@@ -271,6 +271,34 @@ def edge_block(mlp: PackedMLP, ps: torch.Tensor, pd: torch.Tensor, src: torch.Te
     return e_out
 
 
+def edge_stream(mlps: Sequence[PackedMLP], ps_all: torch.Tensor, pd_all: torch.Tensor, src: torch.Tensor,
+                dst: torch.Tensor, e_in: TiledRows, e_out: Optional[TiledRows] = None) -> TiledRows:
+    """All ``len(mlps)`` residual edge updates in one launch (``cgnn_edge_stream``; reference-faithful message only:
+    the caller has already computed every round's ``Ps`` / ``Pd``).  ``ps_all`` / ``pd_all``: ``[rounds, N, H]`` bf16
+    tables in the 16-edge kernel's format."""
+    if not isinstance(e_in, TiledRows):
+        raise CgnnError("edge_stream: edge latents must be TiledRows")
+    src, dst = i32c(src, "src"), i32c(dst, "dst")
+    ne, latent = e_in.n, e_in.width
+    rounds = len(mlps)
+    if e_out is None:
+        e_out = e_in.empty_like()
+    for t, name in ((ps_all, "ps_all"), (pd_all, "pd_all")):
+        require_device(t, name)
+        if t.dtype != torch.bfloat16 or not t.is_contiguous() or t.dim() != 3 or t.shape[0] != rounds:
+            raise CgnnError(f"edge_stream: {name} must be a contiguous bfloat16 [rounds, N, H] table")
+    if any(m.precision != BF16_N16 for m in mlps):
+        raise CgnnError("edge_stream: the edge models must be packed 'bf16_n16'")
+    if src.numel() != ne or dst.numel() != ne or e_out.n != ne or e_out.width != latent:
+        raise CgnnError("edge_stream: src/dst/e_out do not match the edge latents")
+    arr = (Mlp * rounds)(*[m.struct() for m in mlps])
+    with _timed("edge_stream", e_in.device):
+        check(_lib.load().cgnn_edge_stream(arr, rounds, ps_all.data_ptr(), pd_all.data_ptr(),
+                                           ps_all.stride(0), src.data_ptr(), dst.data_ptr(), ne, e_in.buf.data_ptr(),
+                                           e_out.buf.data_ptr(), latent, stream_ptr(e_in.device)), "cgnn_edge_stream")
+    return e_out
+
+
 def aggregate(table, gather: Optional[torch.Tensor], dst: Optional[torch.Tensor], num_nodes: int,
               fixed_k: int = 0, num_edges: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``out[i] = sum_{e: dst[e]==i} table[gather[e] if gather is not None else e]``.  ``table`` is a row-major

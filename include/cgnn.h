@@ -183,6 +183,21 @@ int cgnn_node_block(const cgnn_mlp* mlp, const cgnn_linear* w_x, const cgnn_line
                     const cgnn_linear* ws_next, const cgnn_linear* wd_next, int32_t proj_precision,
                     void* ps_next, void* pd_next, int32_t p_format, void* stream);
 
+/* ---- all rounds of the edge stream in one launch (reference-faithful message only) -----------------------------
+ * graph_network.py:89-90,182 for round = 0..L-1.  Under the reference's aggregation (PyG's default message: sender
+ * NODE latents) the node stream never reads the edge stream, so Ps_r / Pd_r of every round can be computed
+ * first (cgnn_node_block's epilogue) and each edge's latent tile then stays in registers through all L updates
+ *     e <- e + LN_r(MLP_r(Ps_r[src] + Pd_r[dst] + We_r e)),
+ * crossing HBM once instead of L times; the rounds' layers cycle through an LDS ring.  Same arithmetic as
+ * cgnn_edge_block (CGNN_BF16_N16): results are bit-identical to L per-round calls.
+ *   rounds[r]       edge model of round r, CGNN_BF16_N16, layer[0] = the We column block (as for cgnn_edge_block)
+ *   ps_all, pd_all  CGNN_P_BF16_S16 tables of all rounds; round r starts at element r * round_stride
+ *   e_in, e_out     CGNN_TILED32 edge latents (may be the same buffer)
+ * Built for hidden == latent in {32, 64, 128}. */
+int cgnn_edge_stream(const cgnn_mlp* rounds, int32_t num_rounds, const void* ps_all, const void* pd_all,
+                     int64_t round_stride, const int32_t* src, const int32_t* dst, int64_t num_edges,
+                     const float* e_in, float* e_out, int32_t latent, void* stream);
+
 /* ---- backward of a row-wise MLP (+LayerNorm): the node stream of train.py:263 ------------------------
  * In reference-faithful mode only the node path carries gradient (the edge models' parameters get
  * none), so training needs the backward of cgnn_mlp_rows / cgnn_node_block and the transpose of the

@@ -417,6 +417,38 @@ def test_locality_sorted_execution_is_bitwise_equivalent():
         assert torch.equal(a[key], b[key]), key
 
 
+@pytest.mark.parametrize("n,k,latent,nh,steps", [(5000, 16, 128, 2, 3), (300, 8, 128, 2, 10), (3000, 16, 64, 1, 2),
+                                                 (2600, 16, 32, 3, 1), (40000, 16, 128, 2, 2), (777, 8, 64, 2, 5)])
+def test_all_rounds_in_one_launch_is_bitwise_equivalent(n, k, latent, nh, steps):
+    """cgnn_edge_stream (reference data flow: the node stream first, then every edge update with the edge tile in
+    registers) against one launch per round: same arithmetic, so identical bits; and both against the oracle."""
+    snap = synthetic.make_snapshot(n, seed=n)
+    meta = synthetic.make_metadata()
+    d = data_utils.preprocess(snap["Coordinates"][:W], snap["InternalEnergy"][:W], meta, None, None, 0.0, k, 0.01, 1.0)
+    sd = synthetic.make_state_dict(latent, latent, nh, steps, 3)
+    m = graph_network.EncodeProcessDecode(latent, latent, nh, steps, 3)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    m.edge_precision, m.node_precision = "bf16", "fp32x3"
+    with ops.OpTimer() as tm, torch.no_grad():
+        a = m.forward_with_latents(d)
+    assert "edge_stream" in tm.summary() and "edge_block" not in tm.summary()     # the fused path really ran
+    m.fuse_rounds = False
+    with ops.OpTimer() as tm, torch.no_grad():
+        b = m.forward_with_latents(d)
+    assert "edge_block" in tm.summary() and "edge_stream" not in tm.summary()
+    for key in ("acceleration", "temp_rate", "x_latent", "edge_latent"):
+        assert torch.equal(a[key], b[key]), key
+    want = cpu_ref.encode_process_decode(sd, d.x.cpu(), d.edge_index.cpu(), d.edge_attr.cpu(), nh, steps,
+                                         return_latents=True)
+    assert rel_err(a["acceleration"].cpu(), want["acceleration"]) <= TOL
+    assert rel_l2(a["edge_latent"].cpu(), want["edge_latent"]) <= 3e-2             # bf16 edge MLP (SURVEY F8)
+    m.message_source = "edge"                                                      # nodes read the edges: no fusion
+    with ops.OpTimer() as tm, torch.no_grad():
+        m(d)
+    assert "edge_stream" not in tm.summary()
+
+
 def test_on_device_rollout_matches_restatement():
     """render_rollout.rollout counterpart: 3 autoregressive steps on the device vs the oracle's restatement."""
     from cosmology_gnn_simulation_amd import rollout as ro
