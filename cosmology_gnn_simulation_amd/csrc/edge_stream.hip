@@ -13,6 +13,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "n16.hpp"
 
 namespace cgnn {
@@ -22,6 +24,9 @@ namespace cgnn {
 #define CGNN_STREAM_SLOTS 3
 #define CGNN_STREAM_MAX_CHUNKS 64
 #define CGNN_STREAM_MAX_ROUNDS 32
+#ifndef CGNN_STREAM_NB
+#define CGNN_STREAM_NB 3     // LDS fragment groups in flight per wave (dense16)
+#endif
 
 struct StreamArgs {
     const char* w[CGNN_STREAM_MAX_CHUNKS];       // packed CGNN_BF16_N16 layers in consumption order (round-major)
@@ -118,7 +123,7 @@ struct LayerRing {
     }
 };
 
-template <int HT, int DT>
+template <int HT, int DT, bool PMFMA>
 __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
     StreamArgs a, const __bf16* __restrict__ ps_all, const __bf16* __restrict__ pd_all, int64_t round_stride,
     const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t num_edges, const float* e_in, float* e_out) {
@@ -169,6 +174,9 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
     load_p16_operand<HT>(pdo, pd_all, d, q);
     ring.note(2 + DO + 2 * HT);
 
+    // (Tried and dropped: running the two waves of a SIMD half a step apart -- one post-processing the previous layer
+    // on the vector pipe while the other issues this layer's MFMAs -- measured 25.2 ms against 23.5 ms in lockstep at
+    // cfg3; the longer live ranges cost more than the pipes' overlap gained.)
     for (int it = 0; it < iters; ++it) {
         const bool more = it + 1 < iters;
         int64_t tile_n = tile + tr.stride;
@@ -177,13 +185,21 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
         const int64_t tbase_n = (tile_n >> 1) * (32 * D) + n16_lane_offset(c, q, (int)(tile_n & 1));
         int32_t s_n = (int32_t)s, d_n = (int32_t)d;     // widened only where they are used, a tile later
         f32x4 ev_n[DO];
-        for (int r = 0; r < L; ++r) {
+        // One round.  The last round of a tile is its own instantiation: only there are the next tile's latents and
+        // round-0 rows fetched, so ev_n is not carried (and copied) through the other rounds.
+        auto round = [&](int r, auto last_tag) __attribute__((always_inline)) {
+            constexpr bool LAST = decltype(last_tag)::value;
             const LdsVecPtr vr = vbase + r * NV * W;
             bf16x8 oph[HT];
             {
                 const LdsW w0 = ring.wait_ready();
                 f32x4 acc[HO];
-                p16_accumulate<HT>(acc, pso, pdo, sel0, sel1);
+                if (PMFMA) {
+                    p16_accumulate<HT>(acc, pso, pdo, sel0, sel1);
+                } else {
+                    p16_unpack<HT, false>(acc, pso);
+                    p16_unpack<HT, true>(acc, pdo);
+                }
                 if (r == 0 && more) {      // the next tile's edge list entries, a whole tile ahead of their use
                     const int64_t e = tile_n * 16 + c;
                     const int64_t ec = e < num_edges ? e : num_edges - 1;
@@ -192,7 +208,7 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
                     ring.note(2);
                 }
                 // the P registers are free again: fetch the rows of the next round (or of the next tile's round 0)
-                if (r + 1 < L) {
+                if (!LAST) {
                     load_p16_operand<HT>(pso, ps_all + (r + 1) * round_stride, s, q);
                     load_p16_operand<HT>(pdo, pd_all + (r + 1) * round_stride, d, q);
                     ring.note(2 * HT);
@@ -208,24 +224,26 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
                 ring.start_next();     // after the prefetches: the waits the compiler puts before them see only old loads
                 bf16x8 op[DT];
                 operand16<false, DT>(op, ev);
-                dense16<DT, HO, 4>(acc, op, w0, lane);
+                dense16<DT, HO, 4, CGNN_STREAM_NB>(acc, op, w0, lane);
                 operand16<true, HT>(oph, acc);
             }
             for (int l = 1; l < nh; ++l) {
                 const LdsW wl = ring.acquire();
                 f32x4 acc[HO];
                 fill16<HO>(acc, vr + (l - 1) * W, q);
-                dense16<HT, HO, 4>(acc, oph, wl, lane);
+                dense16<HT, HO, 4, CGNN_STREAM_NB>(acc, oph, wl, lane);
                 operand16<true, HT>(oph, acc);
             }
             const LdsW wo = ring.acquire();
             f32x4 out[DO];
             fill16<DO>(out, vr + (nh - 1) * W, q);
-            dense16<HT, DO, 4>(out, oph, wo, lane);
+            dense16<HT, DO, 4, CGNN_STREAM_NB>(out, oph, wo, lane);
             layer_norm16<DO>(out, vr + nh * W, vr + (nh + 1) * W, q);
 #pragma unroll
             for (int o = 0; o < DO; ++o) ev[o] += out[o];
-        }
+        };
+        for (int r = 0; r + 1 < L; ++r) round(r, std::false_type{});
+        round(L - 1, std::true_type{});
         if (valid) {
 #pragma unroll
             for (int o = 0; o < DO; ++o)
@@ -248,7 +266,13 @@ template <int HT, int DT>
 static int launch_stream(const StreamArgs& a, size_t lds, const __bf16* ps, const __bf16* pd, int64_t round_stride,
                          const int32_t* src, const int32_t* dst, int64_t num_edges, const float* e_in, float* e_out,
                          hipStream_t st) {
-    auto kern = edge_stream_n16_kernel<HT, DT>;
+    // P rows through the matrix pipe (measured 24.2 ms against 28.1 ms through the vector pipe at cfg3: the loop is
+    // bound by vector issue).  CGNN_STREAM_PMFMA=0 selects the vector form (developer A/B).
+    static const bool pmfma = [] {
+        const char* v = getenv("CGNN_STREAM_PMFMA");
+        return !(v && atoi(v) == 0);
+    }();
+    auto kern = pmfma ? edge_stream_n16_kernel<HT, DT, true> : edge_stream_n16_kernel<HT, DT, false>;
     if (lds > 48 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),

@@ -23,7 +23,7 @@ typedef const __attribute__((address_space(3))) f32x4* LdsVec4Ptr;
 // Issue order: blocks of OB = 4 output tiles, k-step by k-step, so that consecutive MFMAs write different
 // accumulators and an accumulator recurs only every fourth MFMA (a chain of back-to-back MFMAs on one accumulator
 // exposes the instruction's latency, about twice its issue time for 16x16x32).
-template <int KS, int OT, int GSMAX = 4>
+template <int KS, int OT, int GSMAX = 4, int NB = 2>
 __device__ __forceinline__ void dense16(f32x4 (&out)[OT], const bf16x8 (&in)[KS], const LdsW& wp, int lane) {
     constexpr int M = OT * KS;
     constexpr int OB = (OT % 4 == 0) ? 4 : ((OT % 2 == 0) ? 2 : 1);
@@ -33,22 +33,30 @@ __device__ __forceinline__ void dense16(f32x4 (&out)[OT], const bf16x8 (&in)[KS]
     // issue index t -> (o, s): t = (ob * KS + s) * OB + oo
 #define CGNN_D16_O(t) (((t) / (KS * OB)) * OB + (t) % OB)
 #define CGNN_D16_S(t) (((t) / OB) % KS)
-    bf16x8 buf[2][GS];
+    // NB - 1 groups of fragments in flight ahead of the MFMAs (the LDS latency under load is several groups long)
+    bf16x8 buf[NB][GS];
 #pragma unroll
-    for (int j = 0; j < GS; ++j) buf[0][j] = wp.fetch(CGNN_D16_O(j) * KS + CGNN_D16_S(j), lane);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        if (g + 1 < NG) {
+    for (int p = 0; p < NB - 1; ++p)
+        if (p < NG) {
 #pragma unroll
             for (int j = 0; j < GS; ++j) {
-                const int t = (g + 1) * GS + j;
-                buf[(g + 1) & 1][j] = wp.fetch(CGNN_D16_O(t) * KS + CGNN_D16_S(t), lane);
+                const int t = p * GS + j;
+                buf[p][j] = wp.fetch(CGNN_D16_O(t) * KS + CGNN_D16_S(t), lane);
+            }
+        }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + NB - 1 < NG) {
+#pragma unroll
+            for (int j = 0; j < GS; ++j) {
+                const int t = (g + NB - 1) * GS + j;
+                buf[(g + NB - 1) % NB][j] = wp.fetch(CGNN_D16_O(t) * KS + CGNN_D16_S(t), lane);
             }
         }
 #pragma unroll
         for (int j = 0; j < GS; ++j) {
             const int t = g * GS + j;
-            out[CGNN_D16_O(t)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(buf[g & 1][j], in[CGNN_D16_S(t)],
+            out[CGNN_D16_O(t)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(buf[g % NB][j], in[CGNN_D16_S(t)],
                                                                          out[CGNN_D16_O(t)], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -149,6 +157,29 @@ __device__ __forceinline__ void p16_accumulate(f32x4 (&acc)[2 * KS], const bf16x
 #pragma unroll
     for (int o = 0; o < 2 * KS; ++o)
         acc[o] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((o & 1) ? sel1 : sel0, pd[o >> 1], acc[o], 0, 0, 0);
+}
+
+// The same rows through the vector pipe instead: acc (+)= f32(P row).  Element j of k-step s is tile 2 s + (j >> 2),
+// register j & 3.  (The matrix-pipe form wins where four waves per SIMD keep that pipe fed; with two waves per SIMD
+// and a compute-bound loop the unpack is cheaper than sixteen more MFMAs.)
+template <int KS, bool ADD>
+__device__ __forceinline__ void p16_unpack(f32x4 (&acc)[2 * KS], const bf16x8 (&p)[KS]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const u32x4 w = __builtin_bit_cast(u32x4, p[s]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float lo = __builtin_bit_cast(float, w[t] << 16), hi = __builtin_bit_cast(float, w[t] & 0xffff0000u);
+            f32x4& a = acc[2 * s + (t >> 1)];
+            if (ADD) {
+                a[2 * (t & 1)] += lo;
+                a[2 * (t & 1) + 1] += hi;
+            } else {
+                a[2 * (t & 1)] = lo;
+                a[2 * (t & 1) + 1] = hi;
+            }
+        }
+    }
 }
 
 // LayerNorm over the 16 OT features of each edge; an edge's features live on lanes c, c+16, c+32, c+48.  Two passes

@@ -17,6 +17,8 @@ ap.add_argument("--latent", type=int, default=128)
 ap.add_argument("--edge-precision", default="bf16")
 ap.add_argument("--node-precision", default="fp32")
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--mp-steps", type=int, default=10, help="rounds for the edge_stream line")
+ap.add_argument("--only", default=None, help="time just this op")
 a = ap.parse_args()
 dev = "cuda"
 n, k, d = a.particles, a.neighbors, a.latent
@@ -40,6 +42,8 @@ agg = ops.aggregate(x, src, dst, n, fk)
 
 
 def t(name, fn, nbytes=None, flops=None):
+    if a.only and a.only != name:
+        return
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
@@ -57,6 +61,17 @@ def t(name, fn, nbytes=None, flops=None):
 
 
 E = n * k
+L = a.mp_steps
+mL = graph_network.EncodeProcessDecode(d, d, 2, L, 3)
+mL.load_state_dict(synthetic.make_state_dict(d, d, 2, L, 3))
+mL = mL.to(dev).eval()
+mL.edge_precision, mL.node_precision = a.edge_precision, a.node_precision
+roundsL = mL._pack(17, 4)["rounds"]
+if a.edge_precision == "bf16" and (not a.only or a.only == "edge_stream"):
+    ps_all = torch.randn(L, n, d, device=dev).to(torch.bfloat16)
+    pd_all = torch.randn(L, n, d, device=dev).to(torch.bfloat16)
+    t("edge_stream", lambda: ops.edge_stream([r.edge for r in roundsL], ps_all, pd_all, src, dst, e, e),
+      2 * E * d * 4 + 2 * E * 4 + L * 2 * n * d * 2, L * 6.0 * E * d * d)
 t("edge_block", lambda: ops.edge_block(p.edge, ps, pd, src, dst, e, e, None, True),
   2 * E * d * 4 + 2 * E * 4 + 2 * n * d * 4, 6.0 * E * d * d)
 t("aggregate x_j", lambda: ops.aggregate(x, src, dst, n, fk, E, agg), E * d * 4 + E * 4 + n * d * 4)
