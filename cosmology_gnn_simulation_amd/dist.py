@@ -209,12 +209,17 @@ class ShardedForward:
 
     def _buffers(self, D: int, H: int, dev):
         sh = self.sh
-        key = (D, H, dev, self.model.edge_precision)
+        key = (D, H, dev, self.model.edge_precision, self.fused)
         if self._bufs is None or self._bufs[0] != key:
             x_all = torch.empty((sh.n_local, D), dtype=torch.float32, device=dev)
             pdt = self.P["rounds"][0].p_dtype if self.P["rounds"] else torch.float32
-            ps = torch.empty((sh.n_local, H), dtype=pdt, device=dev)
-            pd = torch.empty((sh.n_owned, H), dtype=pdt, device=dev)
+            if self.fused:      # every round's tables are kept for the one-launch edge stream (same row stride for both)
+                L = len(self.P["rounds"])
+                ps = torch.empty((L, sh.n_local, H), dtype=pdt, device=dev)
+                pd = torch.empty((L, sh.n_local, H), dtype=pdt, device=dev)
+            else:
+                ps = torch.empty((sh.n_local, H), dtype=pdt, device=dev)
+                pd = torch.empty((sh.n_owned, H), dtype=pdt, device=dev)
             agg = torch.empty((sh.n_owned, D), dtype=torch.float32, device=dev)
             self._bufs = (key, x_all, ps, pd, agg)
         return self._bufs[1:]
@@ -226,13 +231,19 @@ class ShardedForward:
         D = m._latent_size
         H = P["rounds"][0].ws.out_dim if P["rounds"] else D
         self.P = P
+        # reference data flow (x_j): the node stream runs round by round with its halo exchanges and leaves every
+        # round's Ps / Pd behind; the edge stream then is one launch (cgnn_edge_stream), as on one GPU
+        self.fused = m._can_fuse_rounds(P["rounds"], D)
         self.x_all, self.ps, self.pd, self.agg = self._buffers(D, H, sh.x_feat.device)
         ops.mlp_rows(P["enc_node"], sh.x_feat, out=self.x_all[:sh.n_owned])
         self._projected = False
+        self._edges_pending = False
         self.el = ops.mlp_rows(P["enc_edge"], sh.edge_attr, tiled=True)
         self.e_upd = self.el.empty_like() if m.message_source == "edge" else None
 
     def round(self, i: int):
+        if self.fused:
+            return self._round_nodes(i)
         m, sh = self.model, self.sh
         rounds = self.P["rounds"]
         p = rounds[i]
@@ -264,7 +275,37 @@ class ShardedForward:
         ops.node_block(p.node, p.wx, p.wa, x_own, self.agg, x_own, True, nxt)
         self._projected = nxt is not None
 
+    def _round_nodes(self, i: int):
+        """Fused mode: the node half of round ``i`` (ghost latents of this round are in ``x_all``)."""
+        sh = self.sh
+        rounds = self.P["rounds"]
+        p = rounds[i]
+        no = sh.n_owned
+        x_own = self.x_all[:no]
+        if sh.n_ghost:
+            ops.project_nodes(p.ws, None, self.x_all[no:], self.ps[i][no:], None, p.p_format)
+        if i == 0:
+            ops.project_nodes(p.ws, p.wd, x_own, self.ps[0][:no], self.pd[0][:no], p.p_format)
+        ops.aggregate(self.x_all, sh.src_local, sh.dst_local, no, sh.k, sh.src_local.numel(), self.agg)
+        nxt = None
+        if i + 1 < len(rounds):
+            q = rounds[i + 1]
+            fused_ok = p.node.precision == _lib.F32X3_N16 and q.ws_fused.precision == _lib.BF16_N16
+            nxt = (q.ws_fused if fused_ok else q.ws, q.wd_fused if fused_ok else q.wd, self.ps[i + 1][:no],
+                   self.pd[i + 1][:no], q.p_format)
+        ops.node_block(p.node, p.wx, p.wa, x_own, self.agg, x_own, True, nxt)
+        self._edges_pending = i + 1 == len(rounds)
+
+    def finish_edges(self):
+        """Fused mode: all edge updates in one launch, once the last round's node half has run."""
+        if self.fused and self._edges_pending:
+            sh = self.sh
+            ops.edge_stream([p.edge for p in self.P["rounds"]], self.ps, self.pd, sh.src_local, sh.dst_local, self.el,
+                            self.el)
+            self._edges_pending = False
+
     def decode(self) -> dict:
+        self.finish_edges()
         x_own = self.x_all[:self.sh.n_owned]
         return {"acceleration": ops.mlp_rows(self.P["dec_acc"], x_own),
                 "temp_rate": ops.mlp_rows(self.P["dec_tr"], x_own)}
