@@ -299,7 +299,8 @@ __global__ __launch_bounds__(CGNN_EDGE_ENC_BLOCK) void edge_encode_n16_kernel(Ml
         layer_norm16<DO>(out, VecSel<true>::gamma(m), VecSel<true>::beta(m), q);
         const int64_t tbase = (tile >> 1) * (32 * D) + n16_lane_offset(c, q, (int)(tile & 1));
 #pragma unroll
-        for (int o = 0; o < DO; ++o) *reinterpret_cast<f32x4*>(y + tbase + n16_tile_offset(o)) = out[o];
+        for (int o = 0; o < DO; ++o)     // written once, read once by the edge stream: keep it out of the caches
+            __builtin_nontemporal_store(out[o], reinterpret_cast<f32x4*>(y + tbase + n16_tile_offset(o)));
     }
 }
 

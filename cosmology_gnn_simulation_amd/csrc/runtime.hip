@@ -177,20 +177,24 @@ __global__ void aggregate_fixedk_kernel(const float* __restrict__ table, const i
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (k == 16 || k == 8) {
             // balanced pairwise tree: the order of the cross-lane reduction in the fused edge kernel, so that the
-            // fused and the stand-alone aggregation are bit-identical.  Eight rows at a time keeps 8 loads in flight.
-            f32x4 half[2];
+            // fused and the stand-alone aggregation are bit-identical.  All k index loads, then all k row loads, are
+            // issued before the first add (16 gathers in flight per lane).
+            int32_t idx[16];
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                if (8 * hh >= k) break;
-                f32x4 v[8];
+            for (int j = 0; j < 16; ++j)
+                if (j < k) idx[j] = gather ? gather[e0 + j] : 0;
+            f32x4 v[16];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int64_t idx = gather ? (int64_t)gather[e0 + 8 * hh + j] : (e0 + 8 * hh + j);
-                    v[j] = *reinterpret_cast<const f32x4*>(table + (idx * chunks + c) * 4);
+            for (int j = 0; j < 16; ++j)
+                if (j < k) {
+                    const int64_t r = gather ? (int64_t)idx[j] : (e0 + j);
+                    v[j] = *reinterpret_cast<const f32x4*>(table + (r * chunks + c) * 4);
                 }
-                half[hh] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-            }
-            acc = k == 16 ? half[0] + half[1] : half[0];
+            const f32x4 h0 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            if (k == 16)
+                acc = h0 + (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+            else
+                acc = h0;
         } else {
 #pragma unroll 8
             for (int j = 0; j < k; ++j) {
