@@ -37,6 +37,14 @@ struct StreamArgs {
     int32_t rounds, nh;
 };
 
+#ifdef CGNN_STREAM_STAMPS   // developer build: s_memtime stamps of one workgroup's waves over their second tile
+__device__ unsigned long long cgnn_stream_stamps[8 * 256];
+#define CGNN_STAMP(k)                                                                        \
+    if (stamp_on && lane == 0 && (k) < 256) cgnn_stream_stamps[wave * 256 + (k)] = __builtin_readcyclecounter()
+#else
+#define CGNN_STAMP(k)
+#endif
+
 typedef __attribute__((address_space(3))) void* LdsVoidPtrS;
 typedef const __attribute__((address_space(1))) void* GlobalVoidPtrS;
 
@@ -56,13 +64,23 @@ struct LayerRing {
     int slot;            // its slot
     int left;            // acquires still to come (over all tiles of this workgroup)
     int after0, after1;  // operations issued after the pieces of `chunk` / of the layer after it
-    __device__ __forceinline__ LayerRing(const StreamArgs& aa, int w, int l, int steps)
-        : a(aa), wave(w), lane(l), count(aa.rounds * (aa.nh + 1)), chunk(0), slot(0), left(steps), after0(0), after1(0) {}
+    const __attribute__((address_space(3))) unsigned long long* tab_ptr;
+    const __attribute__((address_space(3))) uint32_t* tab_bytes;
+    __device__ __forceinline__ LayerRing(const StreamArgs& aa, int w, int l, int steps, char* table)
+        : a(aa), wave(w), lane(l), count(aa.rounds * (aa.nh + 1)), chunk(0), slot(0), left(steps), after0(0), after1(0),
+          tab_ptr((const __attribute__((address_space(3))) unsigned long long*)table),
+          tab_bytes((const __attribute__((address_space(3))) uint32_t*)(table + 8 * CGNN_STREAM_MAX_CHUNKS)) {}
 
+    // The layer table (source pointer, bytes) is read from an LDS copy, not from the kernel arguments: a scalar load in
+    // the loop makes the compiler wait for ALL outstanding LDS reads (s_waitcnt lgkmcnt(0): scalar loads share that
+    // counter and return out of order), which serialised the weight-fragment prefetch of every MFMA group.
     __device__ __forceinline__ int issue(int c, int s) const {
         asm volatile("" ::: "memory");
-        const char* src = a.w[c];
-        const uint32_t nb = a.chunk_bytes[c];
+        const unsigned long long pv = tab_ptr[c];
+        const char* src = reinterpret_cast<const char*>(
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)(pv & 0xffffffffull)));
+        const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab_bytes[c]);
         char* dst = cgnn_smem + s * SLOT_BYTES;
         int n = 0;
         for (uint32_t off = wave * 1024u; off < nb; off += CGNN_STREAM_WAVES * 1024u) {
@@ -104,7 +122,13 @@ struct LayerRing {
         asm volatile("" ::: "memory");
         return LdsW((LdsWeightPtr)(cgnn_smem + slot * SLOT_BYTES));
     }
-    __device__ __forceinline__ void start_next() {
+    // begin_next() does the bookkeeping of the copy two layers ahead and returns this wave's number of 1-KiB pieces;
+    // piece(i) issues one of them (the caller spreads them between its MFMA groups: a vector-memory instruction takes
+    // ~100+ cycles to issue when all eight waves issue theirs at once right after the barrier).
+    const char* nsrc;
+    char* ndst;
+    uint32_t nbytes;
+    __device__ __forceinline__ int begin_next() {
         --left;
         int c2 = chunk + 2;
         if (c2 >= count) c2 -= count;
@@ -112,9 +136,33 @@ struct LayerRing {
         const int s2 = slot == 0 ? 2 : slot - 1;   // (slot + 2) % 3
         after0 = after1;
         after1 = 0;
-        if (left > 1) after0 += issue(c2, s2);
+        int n = 0;
+        if (left > 1) {
+            const unsigned long long pv = tab_ptr[c2];
+            nsrc = reinterpret_cast<const char*>(
+                ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) |
+                (unsigned)__builtin_amdgcn_readfirstlane((int)(pv & 0xffffffffull)));
+            nbytes = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab_bytes[c2]);
+            ndst = cgnn_smem + s2 * SLOT_BYTES;
+            const uint32_t first = wave * 1024u;
+            n = nbytes > first ? (int)((nbytes - first + CGNN_STREAM_WAVES * 1024u - 1) / (CGNN_STREAM_WAVES * 1024u)) : 0;
+            after0 += n;
+        }
         chunk = chunk + 1 == count ? 0 : chunk + 1;
         slot = slot == 2 ? 0 : slot + 1;
+        return n;
+    }
+    __device__ __forceinline__ void piece(int i, int n) const {
+        if (i < n) {
+            const uint32_t off = (wave + CGNN_STREAM_WAVES * i) * 1024u;
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_global_load_lds((GlobalVoidPtrS)(nsrc + off + lane * 16), (LdsVoidPtrS)(ndst + off), 16, 0, 0);
+            asm volatile("" ::: "memory");
+        }
+    }
+    __device__ __forceinline__ void start_next() {
+        const int n = begin_next();
+        for (int i = 0; i < n; ++i) piece(i, n);
     }
     __device__ __forceinline__ LdsW acquire() {
         const LdsW w = wait_ready();
@@ -130,6 +178,7 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
     constexpr int D = 32 * DT, H = 32 * HT, DO = 2 * DT, HO = 2 * HT;
     constexpr int W = H > D ? H : D;
     constexpr uint32_t SLOT = 2u * (uint32_t)(H * (H > D ? H : D));
+    constexpr int PMAX = SLOT / (CGNN_STREAM_WAVES * 1024u) > 0 ? (int)(SLOT / (CGNN_STREAM_WAVES * 1024u)) : 1;   // pieces per wave and layer
     const int L = a.rounds, nh = a.nh, NV = nh + 2;      // vectors per round: biases of layers 1..nh, gamma, beta
     float* vecs = reinterpret_cast<float*>(cgnn_smem + CGNN_STREAM_SLOTS * SLOT);
     for (int idx = threadIdx.x; idx < L * NV * W; idx += blockDim.x) {
@@ -137,6 +186,11 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
         const float* p = v < nh ? a.bias[r * (nh + 1) + v + 1] : (v == nh ? a.gamma[r] : a.beta[r]);
         const int dim = v < nh - 1 ? H : D;
         vecs[idx] = (p != nullptr && i < dim) ? p[i] : 0.f;
+    }
+    char* table = cgnn_smem + CGNN_STREAM_SLOTS * SLOT + (size_t)L * NV * W * 4;     // layer table for the ring
+    if ((int)threadIdx.x < L * (nh + 1)) {
+        reinterpret_cast<unsigned long long*>(table)[threadIdx.x] = (unsigned long long)a.w[threadIdx.x];
+        reinterpret_cast<uint32_t*>(table + 8 * CGNN_STREAM_MAX_CHUNKS)[threadIdx.x] = a.chunk_bytes[threadIdx.x];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
@@ -150,7 +204,7 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
     const int iters = __builtin_amdgcn_readfirstlane(
         first0 < tr.end ? (int)((tr.end - first0 + tr.stride - 1) / tr.stride) : 0);
     if (iters == 0) return;
-    LayerRing<SLOT> ring(a, wave, lane, iters * L * (nh + 1));
+    LayerRing<SLOT> ring(a, wave, lane, iters * L * (nh + 1), table);
     ring.prime();
     const bf16x8 sel0 = p16_selector(lane, 0), sel1 = p16_selector(lane, 1);
     const LdsVecPtr vbase = (LdsVecPtr)(cgnn_smem + CGNN_STREAM_SLOTS * SLOT);
@@ -178,6 +232,10 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
     // on the vector pipe while the other issues this layer's MFMAs -- measured 25.2 ms against 23.5 ms in lockstep at
     // cfg3; the longer live ranges cost more than the pipes' overlap gained.)
     for (int it = 0; it < iters; ++it) {
+#ifdef CGNN_STREAM_STAMPS
+        const bool stamp_on = blockIdx.x == 8 && it == 1;
+        int sk = 0;
+#endif
         const bool more = it + 1 < iters;
         int64_t tile_n = tile + tr.stride;
         const bool valid_n = tile_n < tr.end;
@@ -192,8 +250,11 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
             const LdsVecPtr vr = vbase + r * NV * W;
             bf16x8 oph[HT];
             {
+                CGNN_STAMP(sk++);      // 0: arriving at the layer-0 barrier
                 const LdsW w0 = ring.wait_ready();
+                CGNN_STAMP(sk++);      // 1: released
                 f32x4 acc[HO];
+                p16_ready<HT>(pso, pdo);   // loaded a round ago, before the pieces wait_ready() has just waited for
                 if (PMFMA) {
                     p16_accumulate<HT>(acc, pso, pdo, sel0, sel1);
                 } else {
@@ -207,40 +268,74 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
                     d_n = dst[ec];
                     ring.note(2);
                 }
-                // the P registers are free again: fetch the rows of the next round (or of the next tile's round 0)
-                if (!LAST) {
-                    load_p16_operand<HT>(pso, ps_all + (r + 1) * round_stride, s, q);
-                    load_p16_operand<HT>(pdo, pd_all + (r + 1) * round_stride, d, q);
-                    ring.note(2 * HT);
-                } else if (more) {
-                    load_p16_operand<HT>(pso, ps_all, s_n, q);
-                    load_p16_operand<HT>(pdo, pd_all, d_n, q);
+                if (LAST && more) {
 #pragma unroll
                     for (int o = 0; o < DO; ++o)
                         ev_n[o] = __builtin_nontemporal_load(
                             reinterpret_cast<const f32x4*>(e_in + tbase_n + n16_tile_offset(o)));
-                    ring.note(2 * HT + DO);
+                    ring.note(DO);
                 }
-                ring.start_next();     // after the prefetches: the waits the compiler puts before them see only old loads
+                CGNN_STAMP(sk++);      // 2: P MFMAs issued
+                // The P registers are free again: the rows of the next round (or of the next tile's round 0) and this
+                // wave's pieces of the layer two ahead are requested BETWEEN the MFMA groups below, pieces first.
+                const bool pref = !LAST || more;
+                const __bf16* prs = (LAST ? ps_all : ps_all + (r + 1) * round_stride) +
+                                    (LAST ? (int64_t)s_n : s) * H + 8 * q;
+                const __bf16* prd = (LAST ? pd_all : pd_all + (r + 1) * round_stride) +
+                                    (LAST ? (int64_t)d_n : d) * H + 8 * q;
+                const int np = ring.begin_next();
+                CGNN_STAMP(sk++);      // 3: ring bookkeeping done
                 bf16x8 op[DT];
                 operand16<false, DT>(op, ev);
-                dense16<DT, HO, 4, CGNN_STREAM_NB>(acc, op, w0, lane);
+                constexpr int NG0 = (HO * DT + 3) / 4;
+                dense16_fast<DT, HO, CGNN_STREAM_NB>(acc, op, w0, lane, [&](auto gc) __attribute__((always_inline)) {
+                    constexpr int g = decltype(gc)::value;
+                    if constexpr (g < PMAX) ring.piece(g, np);
+                    static_for_each([&](auto sc) __attribute__((always_inline)) {
+                        constexpr int ks = decltype(sc)::value;
+                        if constexpr ((PMAX + ks < NG0 - 1 ? PMAX + ks : NG0 - 1) == g) {
+                            if (pref) {
+                                pso[ks] = load_p16_step_untracked<ks>(prs);
+                                pdo[ks] = load_p16_step_untracked<ks>(prd);
+                            }
+                        }
+                    }, std::make_integer_sequence<int, HT>{});
+                });
+                if (pref) ring.note(2 * HT);
+                CGNN_STAMP(sk++);      // 4: layer-0 MFMAs issued
                 operand16<true, HT>(oph, acc);
             }
+            auto pieces_only = [&](int np) __attribute__((always_inline)) {
+                return [&ring, np](auto gc) __attribute__((always_inline)) {
+                    constexpr int g = decltype(gc)::value;
+                    if constexpr (g < PMAX) ring.piece(g, np);
+                };
+            };
             for (int l = 1; l < nh; ++l) {
-                const LdsW wl = ring.acquire();
+                CGNN_STAMP(sk++);      // 5: packed, arriving at the hidden-layer barrier
+                const LdsW wl = ring.wait_ready();
+                CGNN_STAMP(sk++);      // 6: released
+                const int np = ring.begin_next();
+                CGNN_STAMP(sk++);      // 7: ring bookkeeping done
                 f32x4 acc[HO];
                 fill16<HO>(acc, vr + (l - 1) * W, q);
-                dense16<HT, HO, 4, CGNN_STREAM_NB>(acc, oph, wl, lane);
+                dense16_fast<HT, HO, CGNN_STREAM_NB>(acc, oph, wl, lane, pieces_only(np));
+                CGNN_STAMP(sk++);      // 8: MFMAs issued
                 operand16<true, HT>(oph, acc);
             }
-            const LdsW wo = ring.acquire();
+            CGNN_STAMP(sk++);          // 9: arriving at the output-layer barrier
+            const LdsW wo = ring.wait_ready();
+            CGNN_STAMP(sk++);          // 10: released
+            const int npo = ring.begin_next();
+            CGNN_STAMP(sk++);          // 11: ring bookkeeping done
             f32x4 out[DO];
             fill16<DO>(out, vr + (nh - 1) * W, q);
-            dense16<HT, DO, 4, CGNN_STREAM_NB>(out, oph, wo, lane);
+            dense16_fast<HT, DO, CGNN_STREAM_NB>(out, oph, wo, lane, pieces_only(npo));
+            CGNN_STAMP(sk++);          // 12: MFMAs issued
             layer_norm16<DO>(out, vr + nh * W, vr + (nh + 1) * W, q);
 #pragma unroll
             for (int o = 0; o < DO; ++o) ev[o] += out[o];
+            CGNN_STAMP(sk++);          // 13: LayerNorm + residual done
         };
         for (int r = 0; r + 1 < L; ++r) round(r, std::false_type{});
         round(L - 1, std::true_type{});
@@ -281,6 +376,21 @@ static int launch_stream(const StreamArgs& a, size_t lds, const __bf16* ps, cons
     }
     const int grid = grid_for_tiles((num_edges + 15) / 16, 1, CGNN_STREAM_WAVES);
     kern<<<grid, CGNN_STREAM_BLOCK, lds, st>>>(a, ps, pd, round_stride, src, dst, num_edges, e_in, e_out);
+#ifdef CGNN_STREAM_STAMPS
+    {
+        static int printed = 0;
+        hipStreamSynchronize(st);
+        if (printed++ == 3) {
+            static unsigned long long h[8 * 256];
+            hipMemcpyFromSymbol(h, HIP_SYMBOL(cgnn_stream_stamps), sizeof(h));
+            for (int k = 0; k < 14 * 3; ++k) {
+                printf("stamp %3d:", k);
+                for (int w = 0; w < 8; ++w) printf(" %8lld", (long long)(h[w * 256 + k] - h[0]));
+                printf("\n");
+            }
+        }
+    }
+#endif
     return check_hip(hipGetLastError(), "cgnn_edge_stream launch");
 }
 
@@ -349,7 +459,7 @@ extern "C" int cgnn_edge_stream(const cgnn_mlp* rounds, int32_t num_rounds, cons
     const int HT = hidden / 32, DT = latent / 32;
     const int wmax = hidden > latent ? hidden : latent;
     const size_t slot = 2u * (size_t)hidden * wmax;
-    const size_t lds = CGNN_STREAM_SLOTS * slot + (size_t)num_rounds * (nh + 2) * wmax * 4;
+    const size_t lds = CGNN_STREAM_SLOTS * slot + (size_t)num_rounds * (nh + 2) * wmax * 4 + 12 * CGNN_STREAM_MAX_CHUNKS;
     if (lds > 160 * 1024) {
         set_error("cgnn_edge_stream: needs %zu bytes of LDS (three %zu-byte layer slots + %d rounds of vectors)", lds, slot,
                   num_rounds);

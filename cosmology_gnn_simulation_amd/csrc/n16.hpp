@@ -13,11 +13,19 @@
 //        phi(s, q, j) = 32 s + 16 (j >> 2) + 4 q + (j & 3),
 // and the weights are packed (CGNN_BF16_N16) with exactly that k order.
 #pragma once
+#include <type_traits>
+#include <utility>
+
 #include "mlp_device.hpp"
 
 namespace cgnn {
 
 typedef const __attribute__((address_space(3))) f32x4* LdsVec4Ptr;
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_each(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
 
 // out[O] += W[16 O .. 16 O + 15, :] . in    fragment m = O * KS + s at wp[m * 64 + lane]
 // Issue order: blocks of OB = 4 output tiles, k-step by k-step, so that consecutive MFMAs write different
@@ -63,6 +71,84 @@ __device__ __forceinline__ void dense16(f32x4 (&out)[OT], const bf16x8 (&in)[KS]
     }
 #undef CGNN_D16_O
 #undef CGNN_D16_S
+}
+
+// dense16 with the LDS fragment pipeline written by hand (ds_read_b128 and counted s_waitcnt lgkmcnt in inline asm).
+// hipcc's own waits in these loops are always lgkmcnt(0): every group of MFMAs then waits for the reads just issued for
+// the groups after it, and the prefetch hides nothing (the kernel sat 40 % of its time in s_waitcnt).  Here NB - 1
+// groups of GS fragments stay in flight: before group g is used the wave waits until at most GS * (groups issued
+// after g) reads are outstanding -- LDS reads return in order.  The caller must not have scalar loads in flight
+// (they share the counter and return out of order); compiler-tracked LDS reads issued earlier are only older entries.
+template <int IMM>
+__device__ __forceinline__ u32x4 lds_read_b128(unsigned addr) {
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(IMM));
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait4(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+
+struct NoBetween {
+    template <class G>
+    __device__ __forceinline__ void operator()(G) const {}
+};
+// `between(group)` runs after each group's MFMAs have been issued: the place for a caller's vector-memory
+// instructions (one or two per group), whose slow issue then overlaps the matrix pipe instead of preceding it.
+template <int KS, int OT, int NB = 3, class Between = NoBetween>
+__device__ __forceinline__ void dense16_pipelined(f32x4 (&out)[OT], const bf16x8 (&in)[KS], const LdsW& wp, int lane,
+                                                  Between&& between = Between{}) {
+    constexpr int M = OT * KS, GS = 4, NG = M / GS;
+    static_assert(OT % 4 == 0 && NB >= 2 && (NB - 1) * GS <= 15, "blocks of four output tiles; lgkmcnt is 4 bits");
+    // issue index t -> (o, s): t = (ob * KS + s) * 4 + oo  (consecutive MFMAs write different accumulators)
+#define CGNN_D16_O(t) (((t) / (KS * 4)) * 4 + (t) % 4)
+#define CGNN_D16_S(t) (((t) / 4) % KS)
+    const unsigned addr = (unsigned)(uintptr_t)wp.p + (unsigned)lane * 16u;
+    u32x4 buf[NB][GS];
+    static_for_each([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        if constexpr (p < NG) {
+            static_for_each([&](auto jc) {
+                constexpr int t = p * GS + decltype(jc)::value;
+                buf[p][decltype(jc)::value] = lds_read_b128<(CGNN_D16_O(t) * KS + CGNN_D16_S(t)) * 1024>(addr);
+            }, std::make_integer_sequence<int, GS>{});
+        }
+    }, std::make_integer_sequence<int, NB - 1>{});
+    static_for_each([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if constexpr (g + NB - 1 < NG) {
+            static_for_each([&](auto jc) {
+                constexpr int t = (g + NB - 1) * GS + decltype(jc)::value;
+                buf[(g + NB - 1) % NB][decltype(jc)::value] =
+                    lds_read_b128<(CGNN_D16_O(t) * KS + CGNN_D16_S(t)) * 1024>(addr);
+            }, std::make_integer_sequence<int, GS>{});
+        }
+        constexpr int newer = ((g + NB - 1 < NG ? g + NB - 1 : NG - 1) - g) * GS;     // reads issued after group g's
+        lds_wait4<newer>(buf[g % NB][0], buf[g % NB][1], buf[g % NB][2], buf[g % NB][3]);
+        static_for_each([&](auto jc) {
+            constexpr int j = decltype(jc)::value, t = g * GS + j;
+            out[CGNN_D16_O(t)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, buf[g % NB][j]), in[CGNN_D16_S(t)], out[CGNN_D16_O(t)], 0, 0, 0);
+        }, std::make_integer_sequence<int, GS>{});
+        between(gc);
+        __builtin_amdgcn_sched_barrier(0);
+    }, std::make_integer_sequence<int, NG>{});
+#undef CGNN_D16_O
+#undef CGNN_D16_S
+}
+
+// `between` is called with integral constants 0 .. groups-1 (see dense16_pipelined); the fallback for narrow layers
+// runs all of them after its MFMAs.
+template <int KS, int OT, int NB = 3, class Between = NoBetween>
+__device__ __forceinline__ void dense16_fast(f32x4 (&out)[OT], const bf16x8 (&in)[KS], const LdsW& wp, int lane,
+                                             Between&& between = Between{}) {
+    if constexpr (OT % 4 == 0) {
+        dense16_pipelined<KS, OT, NB>(out, in, wp, lane, between);
+    } else {
+        dense16<KS, OT, 4, NB>(out, in, wp, lane);
+        static_for_each(between, std::make_integer_sequence<int, (OT * KS + 3) / 4>{});
+    }
 }
 
 // fragments [M0, M1) only, read from a source holding exactly that range
@@ -138,6 +224,37 @@ __device__ __forceinline__ void load_p16_operand(bf16x8 (&op)[KS], const __bf16*
 #pragma unroll
     for (int s = 0; s < KS; ++s) op[s] = p[4 * s];
 }
+// The same loads issued from inline asm, for callers that do their own vmcnt accounting (cgnn_edge_stream): hipcc
+// guards registers loaded across a loop's back edge with s_waitcnt vmcnt(0), which there also waits for the weight
+// ring's LDS-DMA issued moments earlier.  The caller must wait (counted) before p16_ready() hands the registers on.
+template <int KS>
+__device__ __forceinline__ void load_p16_operand_untracked(bf16x8 (&op)[KS], const __bf16* __restrict__ base,
+                                                           int64_t row, int q) {
+    const __bf16* p = base + row * (32 * KS) + q * 8;
+    static_for_each([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        u32x4 r;
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r) : "v"(p), "n"(s * 64));
+        op[s] = __builtin_bit_cast(bf16x8, r);
+    }, std::make_integer_sequence<int, KS>{});
+}
+template <int S>
+__device__ __forceinline__ bf16x8 load_p16_step_untracked(const __bf16* rowq) {   // rowq = base + row*(32 KS) + 8 q
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r) : "v"(rowq), "n"(S * 64));
+    return __builtin_bit_cast(bf16x8, r);
+}
+template <int KS>
+__device__ __forceinline__ void p16_ready(bf16x8 (&a)[KS], bf16x8 (&b)[KS]) {   // orders their uses after this point
+    static_for_each([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        u32x4 x = __builtin_bit_cast(u32x4, a[s]), y = __builtin_bit_cast(u32x4, b[s]);
+        asm volatile("" : "+v"(x), "+v"(y));
+        a[s] = __builtin_bit_cast(bf16x8, x);
+        b[s] = __builtin_bit_cast(bf16x8, y);
+    }, std::make_integer_sequence<int, KS>{});
+}
+
 // A fragment that copies the 16 features {phi(s, q', j') : j' >> 2 == sub} of a k-step to the 16 rows of a C tile:
 // row m = 4 q' + (j' & 3)  <-  k = 8 q' + j' = 8 (m >> 2) + 4 sub + (m & 3); lane (m, q) holds A[m][8 q + j].
 __device__ __forceinline__ bf16x8 p16_selector(int lane, int sub) {
@@ -260,7 +377,8 @@ __device__ __forceinline__ void operand16x3(bf16x8 (&op)[3][KS], const f32x4 (&a
         }
 }
 
-// fragments [M0, M1) of a layer (m = O * KS + s), read from an LDS chunk holding exactly that range
+// fragments [M0, M1) of a layer (m = O * KS + s), read from an LDS chunk holding exactly that range.  (Alternating two
+// accumulators term by term instead of six back-to-back MFMAs on one was measured: 0.95 vs 0.92 ms, no gain.)
 template <int KS, int OT, int M0, int M1>
 __device__ __forceinline__ void dense16x3_part(f32x4 (&out)[OT], const bf16x8 (&in)[3][KS], const LdsWx3& wp, int lane) {
     constexpr int M = M1 - M0;
