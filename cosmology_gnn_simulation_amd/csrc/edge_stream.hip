@@ -153,6 +153,9 @@ struct LayerRing {
         return n;
     }
     __device__ __forceinline__ void piece(int i, int n) const {
+#ifdef CGNN_ABLATE_HALF_DMA     // developer ablation (wrong results): copy only every other piece of each layer
+        if (i & 1) return;
+#endif
         if (i < n) {
             const uint32_t off = (wave + CGNN_STREAM_WAVES * i) * 1024u;
             asm volatile("" ::: "memory");

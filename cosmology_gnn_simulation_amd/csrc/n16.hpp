@@ -378,7 +378,8 @@ __device__ __forceinline__ void operand16x3(bf16x8 (&op)[3][KS], const f32x4 (&a
 }
 
 // fragments [M0, M1) of a layer (m = O * KS + s), read from an LDS chunk holding exactly that range.  (Alternating two
-// accumulators term by term instead of six back-to-back MFMAs on one was measured: 0.95 vs 0.92 ms, no gain.)
+// accumulators term by term instead of six back-to-back MFMAs on one was measured: 0.95 vs 0.92 ms, no gain; so was a
+// hand-written fragment pipeline with counted lgkmcnt waits, as in dense16_pipelined: 0.93 vs 0.94 ms.)
 template <int KS, int OT, int M0, int M1>
 __device__ __forceinline__ void dense16x3_part(f32x4 (&out)[OT], const bf16x8 (&in)[3][KS], const LdsWx3& wp, int lane) {
     constexpr int M = M1 - M0;
