@@ -78,6 +78,7 @@ class Shard:
     send_counts: Optional[List[int]] = None
     x_feat: Optional[torch.Tensor] = None      # [n_owned, F] encoder inputs of the owned particles
     knn_ms: float = 0.0
+    n_interior: int = 0               # owned rows [0, n_interior) have only owned senders (no halo needed)
 
     @property
     def n_local(self) -> int:
@@ -110,6 +111,16 @@ def build_shard(pos_global: torch.Tensor, box_size: float, k: int, world: int, r
     n_owned = owned.numel()
     senders = senders.long()
     remote = owner[senders] != rank
+    # interior receivers (every sender owned) first, boundary receivers last, spatial order kept inside each group:
+    # a round's interior half can then run while the halo exchange is still in flight
+    is_boundary = remote.view(n_owned, k).any(dim=1) if n_owned else remote.new_zeros((0,))
+    n_interior = int((~is_boundary).sum())
+    if 0 < n_interior < n_owned:
+        regroup = torch.cat([torch.nonzero(~is_boundary).squeeze(1), torch.nonzero(is_boundary).squeeze(1)])
+        owned = owned[regroup]
+        senders = senders.view(n_owned, k)[regroup].reshape(-1)
+        edge_attr = edge_attr.view(n_owned, k, -1)[regroup].reshape(n_owned * k, -1).contiguous()
+        remote = remote.view(n_owned, k)[regroup].reshape(-1)
     ghosts = torch.unique(senders[remote])
     g_owner = owner[ghosts].long()
     perm = torch.argsort(g_owner * n_total + ghosts)      # group by owner rank, ascending id inside
@@ -123,7 +134,7 @@ def build_shard(pos_global: torch.Tensor, box_size: float, k: int, world: int, r
     dst_local = torch.arange(n_owned, dtype=torch.int32, device=dev).repeat_interleave(k)
     want = list(torch.split(ghosts, recv_counts))
     sh = Shard(rank, world, k, n_owned, ghosts.numel(), owned, ghosts, src_local, dst_local, edge_attr,
-               recv_counts, want_global=want, knn_ms=knn_ms)
+               recv_counts, want_global=want, knn_ms=knn_ms, n_interior=n_interior)
     sh._g2l = g2l
     return sh
 
@@ -173,7 +184,9 @@ class HaloExchange:
         self.pack = pack_fn or (lambda table, idx, out: ops.gather_rows(table, idx, out))
         self._buf = None
 
-    def __call__(self, table: torch.Tensor) -> None:
+    def start(self, table: torch.Tensor):
+        """Pack the rows the peers asked for and start the all-to-all into ``table``'s ghost block; returns a handle
+        for :meth:`finish`.  Kernels enqueued in between run under the exchange (they must not touch ghost rows)."""
         import torch.distributed as dist
         sh = self.sh
         width = table.shape[1]
@@ -184,13 +197,23 @@ class HaloExchange:
         ghosts = table[sh.n_owned:]
         cdev = _comm_device(table.device, self.group)
         if cdev == table.device:
-            dist.all_to_all_single(ghosts, self._buf, output_split_sizes=sh.recv_counts,
-                                   input_split_sizes=sh.send_counts, group=self.group)
-        else:  # gloo rehearsal with device tensors: stage through host memory
-            recv = torch.empty(ghosts.shape, dtype=ghosts.dtype, device=cdev)
-            dist.all_to_all_single(recv, self._buf.to(cdev), output_split_sizes=sh.recv_counts,
-                                   input_split_sizes=sh.send_counts, group=self.group)
+            work = dist.all_to_all_single(ghosts, self._buf, output_split_sizes=sh.recv_counts,
+                                          input_split_sizes=sh.send_counts, group=self.group, async_op=True)
+            return (work, None, ghosts)
+        # gloo rehearsal with device tensors: stage through host memory
+        recv = torch.empty(ghosts.shape, dtype=ghosts.dtype, device=cdev)
+        work = dist.all_to_all_single(recv, self._buf.to(cdev), output_split_sizes=sh.recv_counts,
+                                      input_split_sizes=sh.send_counts, group=self.group, async_op=True)
+        return (work, recv, ghosts)
+
+    def finish(self, handle) -> None:
+        work, recv, ghosts = handle
+        work.wait()                       # RCCL: the current stream waits for the exchange
+        if recv is not None:
             ghosts.copy_(recv)
+
+    def __call__(self, table: torch.Tensor) -> None:
+        self.finish(self.start(table))
 
 
 # ----------------------------------------------------------------------------
@@ -221,7 +244,10 @@ class ShardedForward:
                 ps = torch.empty((sh.n_local, H), dtype=pdt, device=dev)
                 pd = torch.empty((sh.n_owned, H), dtype=pdt, device=dev)
             agg = torch.empty((sh.n_owned, D), dtype=torch.float32, device=dev)
-            self._bufs = (key, x_all, ps, pd, agg)
+            # fused mode updates the node latents out of place (interior rows are rewritten while boundary receivers
+            # still gather the old ones): a second table, swapped every round
+            x_alt = torch.empty_like(x_all) if self.fused else None
+            self._bufs = (key, x_all, ps, pd, agg, x_alt)
         return self._bufs[1:]
 
     # the pieces are separate methods so that a single-process test can interleave several shards
@@ -234,7 +260,7 @@ class ShardedForward:
         # reference data flow (x_j): the node stream runs round by round with its halo exchanges and leaves every
         # round's Ps / Pd behind; the edge stream then is one launch (cgnn_edge_stream), as on one GPU
         self.fused = m._can_fuse_rounds(P["rounds"], D)
-        self.x_all, self.ps, self.pd, self.agg = self._buffers(D, H, sh.x_feat.device)
+        self.x_all, self.ps, self.pd, self.agg, self.x_alt = self._buffers(D, H, sh.x_feat.device)
         ops.mlp_rows(P["enc_node"], sh.x_feat, out=self.x_all[:sh.n_owned])
         self._projected = False
         self._edges_pending = False
@@ -275,26 +301,33 @@ class ShardedForward:
         ops.node_block(p.node, p.wx, p.wa, x_own, self.agg, x_own, True, nxt)
         self._projected = nxt is not None
 
-    def _round_nodes(self, i: int):
-        """Fused mode: the node half of round ``i`` (ghost latents of this round are in ``x_all``)."""
+    def _round_nodes(self, i: int, part: str = "all"):
+        """Fused mode: the node half of round ``i`` for the owned rows of ``part``: ``"interior"`` (receivers whose
+        senders are all owned: needs no ghost row, runs under the halo exchange), ``"boundary"`` (the rest, after the
+        exchange; also projects the ghost rows) or ``"all"``.  Reads ``x_all``, writes ``x_alt``; the tables swap
+        when the round is complete."""
         sh = self.sh
         rounds = self.P["rounds"]
         p = rounds[i]
-        no = sh.n_owned
-        x_own = self.x_all[:no]
-        if sh.n_ghost:
+        no, ni, k = sh.n_owned, sh.n_interior, sh.k
+        a, b = {"all": (0, no), "interior": (0, ni), "boundary": (ni, no)}[part]
+        if part != "interior" and sh.n_ghost:
             ops.project_nodes(p.ws, None, self.x_all[no:], self.ps[i][no:], None, p.p_format)
-        if i == 0:
-            ops.project_nodes(p.ws, p.wd, x_own, self.ps[0][:no], self.pd[0][:no], p.p_format)
-        ops.aggregate(self.x_all, sh.src_local, sh.dst_local, no, sh.k, sh.src_local.numel(), self.agg)
-        nxt = None
-        if i + 1 < len(rounds):
-            q = rounds[i + 1]
-            fused_ok = p.node.precision == _lib.F32X3_N16 and q.ws_fused.precision == _lib.BF16_N16
-            nxt = (q.ws_fused if fused_ok else q.ws, q.wd_fused if fused_ok else q.wd, self.ps[i + 1][:no],
-                   self.pd[i + 1][:no], q.p_format)
-        ops.node_block(p.node, p.wx, p.wa, x_own, self.agg, x_own, True, nxt)
-        self._edges_pending = i + 1 == len(rounds)
+        if b > a:
+            x_in = self.x_all[a:b]
+            if i == 0:
+                ops.project_nodes(p.ws, p.wd, x_in, self.ps[0][a:b], self.pd[0][a:b], p.p_format)
+            ops.aggregate(self.x_all, sh.src_local[a * k:b * k], None, b - a, k, (b - a) * k, self.agg[a:b])
+            nxt = None
+            if i + 1 < len(rounds):
+                q = rounds[i + 1]
+                fused_ok = p.node.precision == _lib.F32X3_N16 and q.ws_fused.precision == _lib.BF16_N16
+                nxt = (q.ws_fused if fused_ok else q.ws, q.wd_fused if fused_ok else q.wd, self.ps[i + 1][a:b],
+                       self.pd[i + 1][a:b], q.p_format)
+            ops.node_block(p.node, p.wx, p.wa, x_in, self.agg[a:b], self.x_alt[a:b], True, nxt)
+        if part != "interior":
+            self.x_all, self.x_alt = self.x_alt, self.x_all
+            self._edges_pending = i + 1 == len(rounds)
 
     def finish_edges(self):
         """Fused mode: all edge updates in one launch, once the last round's node half has run."""
@@ -314,10 +347,17 @@ class ShardedForward:
         with torch.no_grad():
             self.encode()
             n_rounds = len(self.P["rounds"])
+            overlap = self.fused and hasattr(self.halo, "start") and 0 < self.sh.n_interior
             for i in range(n_rounds):
                 # x_j aggregation and the sender projections both read ghost latents of the current round
-                self.halo(self.x_all)
-                self.round(i)
+                if overlap:     # interior receivers need no ghost row: their half of the round hides the exchange
+                    handle = self.halo.start(self.x_all)
+                    self._round_nodes(i, "interior")
+                    self.halo.finish(handle)
+                    self._round_nodes(i, "boundary")
+                else:
+                    self.halo(self.x_all)
+                    self.round(i)
             return self.decode()
 
 
