@@ -434,7 +434,7 @@ class EncodeProcessDecode(nn.Module):
         nh = rounds[0].edge.num_hidden_layers
         if len(rounds) > 32 or len(rounds) * (nh + 1) > 64 or latent not in (32, 64, 128):
             return False
-        lds = 3 * 2 * latent * latent + len(rounds) * (nh + 2) * latent * 4
+        lds = 3 * 2 * latent * latent + len(rounds) * (nh + 2) * latent * 4 + 12 * 64     # ring + vectors + layer table
         return lds <= 160 * 1024 and all(
             p.edge.precision == _lib.BF16_N16 and p.p_format == _lib.P_BF16_S16 and p.edge.hidden == latent and
             p.edge.num_hidden_layers == nh for p in rounds)

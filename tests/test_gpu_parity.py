@@ -449,6 +449,31 @@ def test_all_rounds_in_one_launch_is_bitwise_equivalent(n, k, latent, nh, steps)
     assert "edge_stream" not in tm.summary()
 
 
+def test_edge_stream_rejects_what_it_cannot_run():
+    d, n, k = 64, 64, 8
+    m = graph_network.EncodeProcessDecode(d, d, 2, 2, 3)
+    m.load_state_dict(synthetic.make_state_dict(d, d, 2, 2, 3))
+    m = m.to(DEV).eval()
+    m.edge_precision, m.node_precision = "bf16", "fp32x3"
+    rounds = m._pack(17, 4)["rounds"]
+    e = ops.TiledRows.from_rows(torch.zeros(n * k, d, device=DEV))
+    src = torch.zeros(n * k, dtype=torch.int32, device=DEV)
+    tab = torch.zeros(2, n, d, dtype=torch.bfloat16, device=DEV)
+    ops.edge_stream([r.edge for r in rounds], tab, tab, src, src, e)                      # fine
+    with pytest.raises(ops.CgnnError, match="rounds"):                                   # table has 2 rounds, 1 given
+        ops.edge_stream([rounds[0].edge], tab, tab, src, src, e)
+    with pytest.raises(ops.CgnnError, match="bfloat16"):
+        ops.edge_stream([r.edge for r in rounds], tab.float(), tab, src, src, e)
+    m32 = graph_network.EncodeProcessDecode(d, d, 2, 2, 3)
+    m32.load_state_dict(synthetic.make_state_dict(d, d, 2, 2, 3))
+    m32 = m32.to(DEV).eval()                                                             # fp32 packing: 32-row kernels
+    with pytest.raises(ops.CgnnError, match="bf16_n16"):
+        ops.edge_stream([r.edge for r in m32._pack(17, 4)["rounds"]], tab, tab, src, src, e)
+    # shapes the fused kernel is not built for fall back to one launch per round inside the model
+    big = graph_network.EncodeProcessDecode(256, 256, 2, 1, 3)
+    assert not big._can_fuse_rounds([], 256)
+
+
 def test_on_device_rollout_matches_restatement():
     """render_rollout.rollout counterpart: 3 autoregressive steps on the device vs the oracle's restatement."""
     from cosmology_gnn_simulation_amd import rollout as ro
