@@ -299,6 +299,20 @@ __device__ __forceinline__ void p16_unpack(f32x4 (&acc)[2 * KS], const bf16x8 (&
     }
 }
 
+// Sum over the four 16-lane rows of a wave (lanes c, c+16, c+32, c+48), result in all of them: gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange rows between two registers on the vector pipe; __shfl_xor(.., 16 / 32)
+// compiles to ds_bpermute_b32, an LDS round trip per step (four dependent ones per LayerNorm).  Same additions, same
+// bits.  Inline asm: with the builtins hipcc (ROCm 7.2) merged the two results when both operands held the same value
+// (scripts/dev/permlane_test.hip).
+__device__ __forceinline__ float rows_sum(float s) {
+    float a = s, b = s;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    a += b;
+    b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 // LayerNorm over the 16 OT features of each edge; an edge's features live on lanes c, c+16, c+32, c+48.  Two passes
 // (mean, then centred squares) on whole f32x4 registers so that hipcc emits packed f32 instructions.
 template <int OT>
@@ -306,9 +320,7 @@ __device__ __forceinline__ void layer_norm16(f32x4 (&a)[OT], LdsVecPtr gamma, Ld
     f32x4 s4 = a[0];
 #pragma unroll
     for (int o = 1; o < OT; ++o) s4 += a[o];
-    float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
+    const float s = rows_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
     const float mean = s * (1.0f / (16 * OT));
     f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -316,9 +328,7 @@ __device__ __forceinline__ void layer_norm16(f32x4 (&a)[OT], LdsVecPtr gamma, Ld
         a[o] -= mean;
         v4 += a[o] * a[o];
     }
-    float v = (v4[0] + v4[1]) + (v4[2] + v4[3]);
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
+    const float v = rows_sum((v4[0] + v4[1]) + (v4[2] + v4[3]));
     const float rstd = 1.0f / sqrtf(v * (1.0f / (16 * OT)) + 1e-5f);
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
@@ -433,8 +443,7 @@ __device__ __forceinline__ void layer_norm16_global(f32x4 (&a)[OT], const float*
     for (int o = 0; o < OT; ++o)
 #pragma unroll
         for (int i = 0; i < 4; ++i) s += a[o][i];
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
+    s = rows_sum(s);
     const float mean = s * (1.0f / (16 * OT));
     float v = 0.f;
 #pragma unroll
@@ -444,8 +453,7 @@ __device__ __forceinline__ void layer_norm16_global(f32x4 (&a)[OT], const float*
             const float d = a[o][i] - mean;
             v += d * d;
         }
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
+    v = rows_sum(v);
     const float rstd = 1.0f / sqrtf(v * (1.0f / (16 * OT)) + 1e-5f);
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
