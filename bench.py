@@ -206,6 +206,29 @@ def main():
             elapsed = time.perf_counter() - t0
         per_op = tm.summary()
 
+    # Reference point inside the same run (single GPU, outside the timed region): the same forward with one
+    # HBM-bound edge-kernel launch per round instead of cgnn_edge_stream.
+    per_round = None
+    if world == 1 and model.fuse_rounds and not args.hip_graph and "edge_stream" in per_op:
+        model.fuse_rounds = False
+        with torch.no_grad():
+            run()
+            torch.cuda.synchronize()
+            with ops.OpTimer() as tm2:
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    run()
+                torch.cuda.synchronize()
+                dt_pr = (time.perf_counter() - t1) / 3
+            eb_calls, eb_ms = tm2.summary()["edge_block"]
+        model.fuse_rounds = True
+        eb_bytes = 2 * e_local * d * 4 + 2 * e_local * 4 + 2 * n_local * h * (2 if args.edge_precision == "bf16" else 4)
+        per_round = {"ms_per_step": round(dt_pr * 1e3, 3), "edge_updates_per_s": e_local * L / dt_pr,
+                     "edge_kernel_avg_ms": round(eb_ms / eb_calls, 4),
+                     "edge_kernel_hbm_GBps": round(eb_bytes / (eb_ms / eb_calls * 1e-3) / 1e9, 1),
+                     "edge_kernel_hbm_frac": round(eb_bytes / (eb_ms / eb_calls * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "note": "same forward, one edge-kernel launch per round (--no-fuse-rounds), 3 steps, untimed region"}
+
     if world > 1:
         import torch.distributed as dist
         cdev = dev if args.backend == "nccl" else torch.device("cpu")
@@ -295,7 +318,7 @@ def main():
                                    f"message_source={args.message_source}",
                        "particles_per_gpu": args.particles, "edges_per_gpu": e_local, "k": k, "latent": d,
                        "mp_steps": L, "parallelism": "single GPU" if world == 1 else f"{world} spatial tiles + halo"},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "one_launch_per_round": per_round,
             "graph_build": {"knn_ms": round(knn_ms, 3), "snapshot_plus_preprocess_s": round(t_build, 3)},
             "end_to_end_from_host": None if world > 1 else {
                 "preprocess_ms_incl_h2d": round(e2e_build * 1e3, 2), "forward_ms_incl_d2h": round(e2e_fwd * 1e3, 2),
