@@ -325,7 +325,13 @@ def main():
                 "edge_updates_per_s": e_local * L / (e2e_build + e2e_fwd),
                 "note": "host window -> H2D -> features + k-NN graph -> forward -> outputs D2H (PCIe inclusive)"},
         }
-        print(json.dumps(line))
+        def _no_nan(o):     # HIP-graph replay has no per-op events: report null, not NaN (strict JSON)
+            if isinstance(o, float) and o != o:
+                return None
+            if isinstance(o, dict):
+                return {k_: _no_nan(v_) for k_, v_ in o.items()}
+            return o
+        print(json.dumps(_no_nan(line)))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
