@@ -203,7 +203,8 @@ __global__ void aggregate_fixedk_kernel(const float* __restrict__ table, const i
                 acc += v;
             }
         }
-        *reinterpret_cast<f32x4*>(out + gid * 4) = acc;
+        // written once and read back once by the node kernel: non-temporal, so the sender rows keep their L2 lines
+        __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(out + gid * 4));
     }
 }
 
