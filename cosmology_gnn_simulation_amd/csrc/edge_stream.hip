@@ -19,7 +19,9 @@
 
 namespace cgnn {
 
+#ifndef CGNN_STREAM_BLOCK
 #define CGNN_STREAM_BLOCK 512
+#endif
 #define CGNN_STREAM_WAVES (CGNN_STREAM_BLOCK / 64)
 #define CGNN_STREAM_SLOTS 3
 #define CGNN_STREAM_MAX_CHUNKS 64
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
     constexpr int D = 32 * DT, H = 32 * HT, DO = 2 * DT, HO = 2 * HT;
     constexpr int W = H > D ? H : D;
     constexpr uint32_t SLOT = 2u * (uint32_t)(H * (H > D ? H : D));
-    constexpr int PMAX = SLOT / (CGNN_STREAM_WAVES * 1024u) > 0 ? (int)(SLOT / (CGNN_STREAM_WAVES * 1024u)) : 1;   // pieces per wave and layer
+    constexpr int PMAX = (int)((SLOT + CGNN_STREAM_WAVES * 1024u - 1) / (CGNN_STREAM_WAVES * 1024u));   // pieces per wave and layer (at most)
     const int L = a.rounds, nh = a.nh, NV = nh + 2;      // vectors per round: biases of layers 1..nh, gamma, beta
     float* vecs = reinterpret_cast<float*>(cgnn_smem + CGNN_STREAM_SLOTS * SLOT);
     for (int idx = threadIdx.x; idx < L * NV * W; idx += blockDim.x) {
@@ -271,6 +273,7 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
                     d_n = dst[ec];
                     ring.note(2);
                 }
+#ifndef CGNN_STREAM_NO_EVN
                 if (LAST && more) {
 #pragma unroll
                     for (int o = 0; o < DO; ++o)
@@ -278,6 +281,7 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
                             reinterpret_cast<const f32x4*>(e_in + tbase_n + n16_tile_offset(o)));
                     ring.note(DO);
                 }
+#endif
                 CGNN_STAMP(sk++);      // 2: P MFMAs issued
                 // The P registers are free again: the rows of the next round (or of the next tile's round 0) and this
                 // wave's pieces of the layer two ahead are requested BETWEEN the MFMA groups below, pieces first.
@@ -349,8 +353,15 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
             ring.note(DO);
         }
         if (more) {
+#ifndef CGNN_STREAM_NO_EVN
 #pragma unroll
             for (int o = 0; o < DO; ++o) ev[o] = ev_n[o];
+#else       // (developer variant for smaller register budgets: the next tile's latents are fetched only now)
+#pragma unroll
+            for (int o = 0; o < DO; ++o)
+                ev[o] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(e_in + tbase_n + n16_tile_offset(o)));
+            ring.note(DO);
+#endif
             tile = tile_n;
             tbase = tbase_n;
             valid = valid_n;
