@@ -132,7 +132,8 @@ __device__ __forceinline__ void dense16_pipelined(f32x4 (&out)[OT], const bf16x8
                 __builtin_bit_cast(bf16x8, buf[g % NB][j]), in[CGNN_D16_S(t)], out[CGNN_D16_O(t)], 0, 0, 0);
         }, std::make_integer_sequence<int, GS>{});
         between(gc);
-        __builtin_amdgcn_sched_barrier(0);
+        // no sched_barrier here: the asm statements keep the reads, waits and MFMA groups in order by themselves, and
+        // the compiler may slide independent vector work between the groups (23.7 -> 23.2 ms for cgnn_edge_stream)
     }, std::make_integer_sequence<int, NG>{});
 #undef CGNN_D16_O
 #undef CGNN_D16_S
