@@ -27,7 +27,7 @@ namespace cgnn {
 #define CGNN_STREAM_MAX_CHUNKS 64
 #define CGNN_STREAM_MAX_ROUNDS 32
 #ifndef CGNN_STREAM_NB
-#define CGNN_STREAM_NB 3     // LDS fragment groups in flight per wave (dense16)
+#define CGNN_STREAM_NB 2     // buffered LDS fragment groups per wave (one in flight ahead; 3 and 4 measured 1.5 % and 4 % slower)
 #endif
 
 struct StreamArgs {
