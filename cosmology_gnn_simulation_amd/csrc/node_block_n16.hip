@@ -22,13 +22,11 @@ template <int T, int PFMT>
 __global__ __launch_bounds__(CGNN_NODE_N16_BLOCK) void node_block_x3n16_kernel(
     MlpDev m, X3Chunks chunks, const float* __restrict__ b1, const float* x, const float* __restrict__ agg, int64_t n,
     float* x_out, int residual, const float* __restrict__ bd_next, __bf16* __restrict__ ps_next,
-    __bf16* __restrict__ pd_next) {
+    __bf16* __restrict__ pd_next, const void* __restrict__ ws_w, const void* __restrict__ wd_w) {
     constexpr int D = 32 * T, OT = 2 * T, KS = T;
     constexpr int M = OT * KS;                                     // fragments per layer
     constexpr int CH = (M < CGNN_NODE_N16_CHUNK_FRAGS) ? M : CGNN_NODE_N16_CHUNK_FRAGS;
     constexpr int NCH = M / CH;                                    // 1, 1, 4 for T = 1, 2, 4
-    constexpr int PCH = (M < 16) ? M : 16;                         // projection (one-term bf16) chunks: <= 16 KB
-    constexpr int PNCH = M / PCH;
     constexpr int WAVES = CGNN_NODE_N16_BLOCK / 64;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -44,6 +42,20 @@ __global__ __launch_bounds__(CGNN_NODE_N16_BLOCK) void node_block_x3n16_kernel(
         bt = (int64_t)b * WAVES;
         bend = tiles;
         bstride = (int64_t)nb * WAVES;
+    }
+    // The two one-term projection layers (next round's Ws / Wd, M KiB each) stay resident behind the ring's two
+    // slots for the whole launch: they were 64 KB of the 448 KB each workgroup step pulled through the ring, and four of
+    // its twelve barriers.
+    const LdsWeightPtr proj_w = (LdsWeightPtr)(cgnn_smem + 2 * CGNN_NODE_N16_CHUNK_BYTES);
+    if (ps_next != nullptr) {
+        const u32x4* s0 = reinterpret_cast<const u32x4*>(ws_w);
+        const u32x4* s1 = reinterpret_cast<const u32x4*>(wd_w);
+        u32x4* d0 = reinterpret_cast<u32x4*>(cgnn_smem + 2 * CGNN_NODE_N16_CHUNK_BYTES);
+        for (int i = threadIdx.x; i < M * 64; i += blockDim.x) {
+            d0[i] = s0[i];
+            d0[M * 64 + i] = s1[i];
+        }
+        __syncthreads();
     }
     WeightRingT<CGNN_NODE_N16_CHUNK_BYTES, 2> ring(chunks, wave, lane);
     if (bt < bend) ring.issue(0);
@@ -102,28 +114,19 @@ __global__ __launch_bounds__(CGNN_NODE_N16_BLOCK) void node_block_x3n16_kernel(
             if (residual) out[o] += xv[o];
             if (live) *reinterpret_cast<f32x4*>(x_out + row * D + 16 * o + foff) = out[o];
         }
-#define CGNN_N16_PROJ(ACC)                                                                   \
-    {                                                                                            \
-        const LdsW p0_(ring.acquire(more));                                                      \
-        dense16_part<KS, OT, 0, PCH>(ACC, opb, p0_, lane);                                       \
-        if (PNCH == 2) {                                                                         \
-            const LdsW p1_(ring.acquire(more));                                                  \
-            dense16_part<KS, OT, (PNCH == 2 ? PCH : 0), (PNCH == 2 ? 2 * PCH : PCH)>(ACC, opb, p1_, lane); \
-        }                                                                                        \
-    }
-        if (ps_next != nullptr) {   // block-uniform: the projection chunks are part of the ring sequence
+        if (ps_next != nullptr) {   // block-uniform
             bf16x8 opb[KS];
             operand16<false, KS>(opb, out);
             {
                 f32x4 acc[OT];
                 fill16_global<OT>(acc, nullptr, q);
-                CGNN_N16_PROJ(acc)
+                dense16<KS, OT>(acc, opb, LdsW(proj_w), lane);
                 if (live) store_p16<PFMT, OT>(acc, ps_next, row, q);
             }
             {
                 f32x4 acc[OT];
                 fill16_global<OT>(acc, bd_next, q);
-                CGNN_N16_PROJ(acc)
+                dense16<KS, OT>(acc, opb, LdsW(proj_w + M * 64), lane);
                 if (live) store_p16<PFMT, OT>(acc, pd_next, row, q);
             }
         }
@@ -132,15 +135,17 @@ __global__ __launch_bounds__(CGNN_NODE_N16_BLOCK) void node_block_x3n16_kernel(
 
 template <int T, int PFMT>
 static int launch(const MlpDev& m, const X3Chunks& ch, const float* b1, const float* x, const float* agg, int64_t n,
-                  float* x_out, int residual, const float* bd, void* ps, void* pd, hipStream_t st) {
+                  float* x_out, int residual, const float* bd, void* ps, void* pd, const void* ws_w, const void* wd_w,
+                  hipStream_t st) {
     auto kern = node_block_x3n16_kernel<T, PFMT>;
-    const int lds = 2 * CGNN_NODE_N16_CHUNK_BYTES;
+    const int lds = 2 * CGNN_NODE_N16_CHUNK_BYTES + (ps ? 2 * (2 * T * T) * 1024 : 0);
     int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds),
                        "hipFuncSetAttribute(node_block_x3n16)");
     if (rc != CGNN_OK) return rc;
     const int grid = grid_for_tiles((n + 15) / 16, CGNN_NODE_N16_BPC, CGNN_NODE_N16_BLOCK / 64);
-    kern<<<grid, CGNN_NODE_N16_BLOCK, lds, st>>>(m, ch, b1, x, agg, n, x_out, residual, bd, (__bf16*)ps, (__bf16*)pd);
+    kern<<<grid, CGNN_NODE_N16_BLOCK, lds, st>>>(m, ch, b1, x, agg, n, x_out, residual, bd, (__bf16*)ps, (__bf16*)pd, ws_w,
+                                                 wd_w);
     return check_hip(hipGetLastError(), "cgnn_node_block(x3 n16) launch");
 }
 
@@ -162,23 +167,17 @@ int node_block_x3n16(const MlpDev& m, const cgnn_linear* w_x, const cgnn_linear*
     add_layer(w_x->w);
     add_layer(w_agg->w);
     for (int l = 1; l <= m.nh; ++l) add_layer(m.w[l]);
-    if (fuse) {
-        const int PCH = M < 16 ? M : 16;
-        for (const cgnn_linear* L : {ws_next, wd_next})
-            for (int c = 0; c < M / PCH; ++c) {
-                ch.src[ch.count] = reinterpret_cast<const char*>(L->w) + (size_t)c * PCH * 1024;
-                ch.bytes[ch.count++] = (uint32_t)PCH * 1024;
-            }
-    }
     const float* b1 = w_x->b ? w_x->b : w_agg->b;
     const float* bd = fuse ? wd_next->b : nullptr;
     void* ps = fuse ? ps_next : nullptr;
     void* pd = fuse ? pd_next : nullptr;
     const bool s16 = fuse && p_format == CGNN_P_BF16_S16;
+    const void* wsw = fuse ? ws_next->w : nullptr;
+    const void* wdw = fuse ? wd_next->w : nullptr;
 #define CGNN_GO(Tt)                                                                                           \
     if (T == Tt)                                                                                               \
-        return s16 ? launch<Tt, CGNN_P_BF16_S16>(m, ch, b1, x, agg, n, x_out, residual, bd, ps, pd, st)         \
-                   : launch<Tt, CGNN_P_BF16_S32>(m, ch, b1, x, agg, n, x_out, residual, bd, ps, pd, st);
+        return s16 ? launch<Tt, CGNN_P_BF16_S16>(m, ch, b1, x, agg, n, x_out, residual, bd, ps, pd, wsw, wdw, st) \
+                   : launch<Tt, CGNN_P_BF16_S32>(m, ch, b1, x, agg, n, x_out, residual, bd, ps, pd, wsw, wdw, st);
     CGNN_GO(1) CGNN_GO(2) CGNN_GO(4)
 #undef CGNN_GO
     set_error("cgnn_node_block: no CGNN_F32X3_N16 kernel for latent=%d", 32 * T);

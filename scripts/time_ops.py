@@ -76,6 +76,11 @@ t("edge_block", lambda: ops.edge_block(p.edge, ps, pd, src, dst, e, e, None, Tru
   2 * E * d * 4 + 2 * E * 4 + 2 * n * d * 4, 6.0 * E * d * d)
 t("aggregate x_j", lambda: ops.aggregate(x, src, dst, n, fk, E, agg), E * d * 4 + E * 4 + n * d * 4)
 t("node_block", lambda: ops.node_block(p.node, p.wx, p.wa, x, agg, x, True), 3 * n * d * 4, 8.0 * n * d * d)
+if len(roundsL) > 1 and roundsL[0].node.precision == 4:      # F32X3_N16: projections of the next round fused in
+    q_ = roundsL[1]
+    t("node_block+proj", lambda: ops.node_block(roundsL[0].node, roundsL[0].wx, roundsL[0].wa, x, agg, x, True,
+                                                (q_.ws_fused, q_.wd_fused, ps, pd, q_.p_format)),
+      3 * n * d * 4 + 2 * n * d * 2, 8.0 * n * d * d)
 t("project_nodes", lambda: ops.project_nodes(p.ws, p.wd, x, ps, pd, p.p_format), 3 * n * d * 4, 4.0 * n * d * d)
 t("enc_edge", lambda: ops.mlp_rows(P["enc_edge"], ea, out=e), E * (16 + d * 4), 2.0 * E * (32 * d + 2 * d * d))
 t("enc_node", lambda: ops.mlp_rows(P["enc_node"], xf, out=x), n * (68 + d * 4), 2.0 * n * (32 * d + 2 * d * d))
