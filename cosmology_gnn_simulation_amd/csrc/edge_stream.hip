@@ -233,6 +233,9 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
     load_p16_operand<HT>(pdo, pd_all, d, q);
     ring.note(2 + DO + 2 * HT);
 
+    // (Tried and dropped: TWO tiles per wave per ring step, the second tile's f32 latents parked in LDS behind a
+    // two-slot ring -- half the barriers and LDS-DMA pieces per edge, bit-identical results, but 256 registers with
+    // spills and an exposed tile switch: 22.7 ms against 22.1 ms for this kernel on the same GPU.)
     // (Tried and dropped: running the two waves of a SIMD half a step apart -- one post-processing the previous layer
     // on the vector pipe while the other issues this layer's MFMAs -- measured 25.2 ms against 23.5 ms in lockstep at
     // cfg3; the longer live ranges cost more than the pipes' overlap gained.)
