@@ -265,19 +265,25 @@ def main():
             # the matrix pipe.  Algorithmic bytes: e read + written once, src/dst, and every round's Ps/Pd tables once.
             calls, total_ms = per_op["edge_stream"]
             edge_ms = total_ms / calls
-            alg_bytes = 2 * e_local * d * 4 + 2 * e_local * 4 + L * 2 * n_local * h * sz_p
+            # the edge encoder runs inside the same launch when it has the rounds' shape (then only the node encoder
+            # and the two decoders are left as mlp_rows calls): its output is never written, its input is E x 4 floats
+            enc_fused = per_op.get("mlp_rows", (0, 0.0))[0] <= 3 * calls
+            enc_flops = 2.0 * e_local * (4 * h + (args.hidden_layers - 1) * h * h + h * d) if enc_fused else 0.0
+            alg_bytes = ((e_local * d * 4 + e_local * 16) if enc_fused else 2 * e_local * d * 4) + 2 * e_local * 4 + \
+                L * 2 * n_local * h * sz_p
             # achieved = ALGORITHMIC flops per launch / launch time (10 D^2 = 163,840 FLOP per edge update at
             # D = 128 in the reference formulation, x E*L edge updates per launch).  The split first layer executes 6/10 of
             # them; that rate is reported next to it.
-            tf = L * flops_alg / (edge_ms * 1e-3) / 1e12
-            tf_exec = L * flops_exec / (edge_ms * 1e-3) / 1e12
+            tf = (L * flops_alg + enc_flops) / (edge_ms * 1e-3) / 1e12
+            tf_exec = (L * flops_exec + enc_flops) / (edge_ms * 1e-3) / 1e12
             roofline = {"kernel": f"cgnn::edge_stream_n16_kernel<{h // 32},{d // 32}>", "bound": "mfma",
                         "achieved": round(tf, 1), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(tf / mfma_peak, 4),
-                        "traffic": traffic_db.get(f"edge_stream:{n_local}:{k}:{d}:{L}"),
+                        "traffic": traffic_db.get(f"edge_stream{'+enc' if enc_fused else ''}:{n_local}:{k}:{d}:{L}"),
                         "avg_launch_ms": round(edge_ms, 4), "launches": calls,
-                        "algorithmic_flops_per_launch": L * flops_alg,
-                        "flops_per_edge_update": flops_alg / e_local,
-                        "executed": {"flops_per_launch": L * flops_exec, "tflops": round(tf_exec, 1),
+                        "algorithmic_flops_per_launch": L * flops_alg + enc_flops,
+                        "flops_per_edge_update": flops_alg / e_local, "edge_encoder_in_launch": bool(enc_fused),
+                        "encoder_flops_per_launch": enc_flops,
+                        "executed": {"flops_per_launch": L * flops_exec + enc_flops, "tflops": round(tf_exec, 1),
                                      "frac": round(tf_exec / mfma_peak, 4),
                                      "note": "MFMA flops actually issued for the edge MLPs (first Linear split by columns: "
                                              "the sender/receiver thirds are per-node work in the node kernel's epilogue)"},

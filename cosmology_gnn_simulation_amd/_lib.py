@@ -81,7 +81,7 @@ def load() -> C.CDLL:
     lib.cgnn_relayout.argtypes = [vp, i32, vp, i32, i64, i32, vp]
     lib.cgnn_project_nodes.argtypes = [C.POINTER(Linear), C.POINTER(Linear), i32, vp, i64, vp, vp, i32, vp]
     lib.cgnn_edge_block.argtypes = [C.POINTER(Mlp), vp, vp, vp, vp, i64, vp, vp, vp, i32, i32, vp, vp, i32, vp]
-    lib.cgnn_edge_stream.argtypes = [C.POINTER(Mlp), i32, vp, vp, i64, vp, vp, i64, vp, vp, i32, vp]
+    lib.cgnn_edge_stream.argtypes = [C.POINTER(Mlp), i32, vp, vp, i64, vp, vp, i64, vp, vp, i32, C.POINTER(Mlp), vp, i32, vp]
     lib.cgnn_aggregate.argtypes = [vp, i32, vp, vp, i64, i32, i64, i32, vp, vp]
     lib.cgnn_node_block.argtypes = [C.POINTER(Mlp), C.POINTER(Linear), C.POINTER(Linear), vp, vp, i64, vp, i32, i32,
                                     C.POINTER(Linear), C.POINTER(Linear), i32, vp, vp, i32, vp]

@@ -37,6 +37,11 @@ struct StreamArgs {
     const float* beta[CGNN_STREAM_MAX_ROUNDS];
     uint32_t chunk_bytes[CGNN_STREAM_MAX_CHUNKS];
     int32_t rounds, nh;
+    // optional edge encoder (graph_network.py:57) run on each tile before round 0: its nh + 1 layers are entries
+    // 0 .. enc_layers-1 of w / bias / chunk_bytes, the rounds' layers follow
+    int32_t enc_layers, enc_in_dim;
+    const float* enc_gamma;
+    const float* enc_beta;
 };
 
 #ifdef CGNN_STREAM_STAMPS   // developer build: s_memtime stamps of one workgroup's waves over their second tile
@@ -69,7 +74,8 @@ struct LayerRing {
     const __attribute__((address_space(3))) unsigned long long* tab_ptr;
     const __attribute__((address_space(3))) uint32_t* tab_bytes;
     __device__ __forceinline__ LayerRing(const StreamArgs& aa, int w, int l, int steps, char* table)
-        : a(aa), wave(w), lane(l), count(aa.rounds * (aa.nh + 1)), chunk(0), slot(0), left(steps), after0(0), after1(0),
+        : a(aa), wave(w), lane(l), count(aa.enc_layers + aa.rounds * (aa.nh + 1)), chunk(0), slot(0), left(steps), after0(0),
+          after1(0),
           tab_ptr((const __attribute__((address_space(3))) unsigned long long*)table),
           tab_bytes((const __attribute__((address_space(3))) uint32_t*)(table + 8 * CGNN_STREAM_MAX_CHUNKS)) {}
 
@@ -176,10 +182,13 @@ struct LayerRing {
     }
 };
 
-template <int HT, int DT, bool PMFMA>
+// ENC: the tile's initial latents come from the edge encoder run in-kernel on `attr` (edge features, <= 32 per edge)
+// instead of being read from e_in: the encoder's E x D f32 output is then never written or read.
+template <int HT, int DT, bool PMFMA, bool ENC>
 __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
     StreamArgs a, const __bf16* __restrict__ ps_all, const __bf16* __restrict__ pd_all, int64_t round_stride,
-    const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t num_edges, const float* e_in, float* e_out) {
+    const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t num_edges, const float* e_in, float* e_out,
+    const float* __restrict__ attr, int ld_attr) {
     constexpr int D = 32 * DT, H = 32 * HT, DO = 2 * DT, HO = 2 * HT;
     constexpr int W = H > D ? H : D;
     constexpr uint32_t SLOT = 2u * (uint32_t)(H * (H > D ? H : D));
@@ -188,12 +197,23 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
     float* vecs = reinterpret_cast<float*>(cgnn_smem + CGNN_STREAM_SLOTS * SLOT);
     for (int idx = threadIdx.x; idx < L * NV * W; idx += blockDim.x) {
         const int r = idx / (NV * W), v = (idx / W) % NV, i = idx % W;
-        const float* p = v < nh ? a.bias[r * (nh + 1) + v + 1] : (v == nh ? a.gamma[r] : a.beta[r]);
+        const float* p = v < nh ? a.bias[a.enc_layers + r * (nh + 1) + v + 1] : (v == nh ? a.gamma[r] : a.beta[r]);
         const int dim = v < nh - 1 ? H : D;
         vecs[idx] = (p != nullptr && i < dim) ? p[i] : 0.f;
     }
-    char* table = cgnn_smem + CGNN_STREAM_SLOTS * SLOT + (size_t)L * NV * W * 4;     // layer table for the ring
-    if ((int)threadIdx.x < L * (nh + 1)) {
+    // encoder vectors: biases of its layers 0 .. nh, gamma, beta
+    constexpr int ENC_EXTRA = ENC ? 1 : 0;
+    float* evecs = vecs + L * NV * W;
+    if (ENC) {
+        for (int idx = threadIdx.x; idx < (nh + 3) * W; idx += blockDim.x) {
+            const int v = idx / W, i = idx % W;
+            const float* p = v <= nh ? a.bias[v] : (v == nh + 1 ? a.enc_gamma : a.enc_beta);
+            const int dim = v < nh ? H : D;
+            evecs[idx] = (p != nullptr && i < dim) ? p[i] : 0.f;
+        }
+    }
+    char* table = cgnn_smem + CGNN_STREAM_SLOTS * SLOT + ((size_t)L * NV + ENC_EXTRA * (nh + 3)) * W * 4;   // layer table
+    if ((int)threadIdx.x < a.enc_layers + L * (nh + 1)) {
         reinterpret_cast<unsigned long long*>(table)[threadIdx.x] = (unsigned long long)a.w[threadIdx.x];
         reinterpret_cast<uint32_t*>(table + 8 * CGNN_STREAM_MAX_CHUNKS)[threadIdx.x] = a.chunk_bytes[threadIdx.x];
     }
@@ -209,7 +229,7 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
     const int iters = __builtin_amdgcn_readfirstlane(
         first0 < tr.end ? (int)((tr.end - first0 + tr.stride - 1) / tr.stride) : 0);
     if (iters == 0) return;
-    LayerRing<SLOT> ring(a, wave, lane, iters * L * (nh + 1), table);
+    LayerRing<SLOT> ring(a, wave, lane, iters * (a.enc_layers + L * (nh + 1)), table);
     ring.prime();
     const bf16x8 sel0 = p16_selector(lane, 0), sel1 = p16_selector(lane, 1);
     const LdsVecPtr vbase = (LdsVecPtr)(cgnn_smem + CGNN_STREAM_SLOTS * SLOT);
@@ -225,13 +245,30 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
         d = dst[ec];
     }
     f32x4 ev[DO];
+    float at[8];          // ENC: this lane's edge features phi(0, q, j) of edge c (zero beyond the encoder's fan-in)
+    const int enc_in = a.enc_in_dim;
+    auto load_attr = [&](float (&dstv)[8], int64_t t) __attribute__((always_inline)) {
+        const int64_t e = t * 16 + c;
+        const int64_t ec = e < num_edges ? e : num_edges - 1;
 #pragma unroll
-    for (int o = 0; o < DO; ++o)
-        ev[o] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(e_in + tbase + n16_tile_offset(o)));
+        for (int j = 0; j < 8; ++j) {
+            const int f = 16 * (j >> 2) + 4 * q + (j & 3);
+            dstv[j] = f < enc_in ? attr[ec * ld_attr + f] : 0.f;
+        }
+    };
+    if (ENC) {
+        load_attr(at, tile);
+        ring.note(8);
+    } else {
+#pragma unroll
+        for (int o = 0; o < DO; ++o)
+            ev[o] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(e_in + tbase + n16_tile_offset(o)));
+        ring.note(DO);
+    }
     bf16x8 pso[HT], pdo[HT];
     load_p16_operand<HT>(pso, ps_all, s, q);
     load_p16_operand<HT>(pdo, pd_all, d, q);
-    ring.note(2 + DO + 2 * HT);
+    ring.note(2 + 2 * HT);
 
     // (Tried and dropped: TWO tiles per wave per ring step, the second tile's f32 latents parked in LDS behind a
     // two-slot ring -- half the barriers and LDS-DMA pieces per edge, bit-identical results, but 256 registers with
@@ -251,6 +288,7 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
         const int64_t tbase_n = (tile_n >> 1) * (32 * D) + n16_lane_offset(c, q, (int)(tile_n & 1));
         int32_t s_n = (int32_t)s, d_n = (int32_t)d;     // widened only where they are used, a tile later
         f32x4 ev_n[DO];
+        float at_n[8];
         // One round.  The last round of a tile is its own instantiation: only there are the next tile's latents and
         // round-0 rows fetched, so ev_n is not carried (and copied) through the other rounds.
         auto round = [&](int r, auto last_tag) __attribute__((always_inline)) {
@@ -278,11 +316,16 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
                 }
 #ifndef CGNN_STREAM_NO_EVN
                 if (LAST && more) {
+                    if (ENC) {
+                        load_attr(at_n, tile_n);
+                        ring.note(8);
+                    } else {
 #pragma unroll
-                    for (int o = 0; o < DO; ++o)
-                        ev_n[o] = __builtin_nontemporal_load(
-                            reinterpret_cast<const f32x4*>(e_in + tbase_n + n16_tile_offset(o)));
-                    ring.note(DO);
+                        for (int o = 0; o < DO; ++o)
+                            ev_n[o] = __builtin_nontemporal_load(
+                                reinterpret_cast<const f32x4*>(e_in + tbase_n + n16_tile_offset(o)));
+                        ring.note(DO);
+                    }
                 }
 #endif
                 CGNN_STAMP(sk++);      // 2: P MFMAs issued
@@ -347,6 +390,37 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
             for (int o = 0; o < DO; ++o) ev[o] += out[o];
             CGNN_STAMP(sk++);          // 13: LayerNorm + residual done
         };
+        if (ENC) {     // edge encoder: MLP + LayerNorm of the edge features, no residual (its layers lead the ring)
+            const LdsVecPtr ve = vbase + L * NV * W;
+            bf16x8 oph[HT];
+            {
+                const LdsW w0 = ring.acquire();
+                bf16x8 op[1];
+                {
+                    u32x4 v;
+                    v[0] = pack_bf16(at[0], at[1]);
+                    v[1] = pack_bf16(at[2], at[3]);
+                    v[2] = pack_bf16(at[4], at[5]);
+                    v[3] = pack_bf16(at[6], at[7]);
+                    op[0] = __builtin_bit_cast(bf16x8, v);
+                }
+                f32x4 acc[HO];
+                fill16<HO>(acc, ve, q);
+                dense16_fast<1, HO, CGNN_STREAM_NB>(acc, op, w0, lane);
+                operand16<true, HT>(oph, acc);
+            }
+            for (int l = 1; l < nh; ++l) {
+                const LdsW wl = ring.acquire();
+                f32x4 acc[HO];
+                fill16<HO>(acc, ve + l * W, q);
+                dense16_fast<HT, HO, CGNN_STREAM_NB>(acc, oph, wl, lane);
+                operand16<true, HT>(oph, acc);
+            }
+            const LdsW wo = ring.acquire();
+            fill16<DO>(ev, ve + nh * W, q);
+            dense16_fast<HT, DO, CGNN_STREAM_NB>(ev, oph, wo, lane);
+            layer_norm16<DO>(ev, ve + (nh + 1) * W, ve + (nh + 2) * W, q);
+        }
         for (int r = 0; r + 1 < L; ++r) round(r, std::false_type{});
         round(L - 1, std::true_type{});
         if (valid) {
@@ -357,8 +431,13 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
         }
         if (more) {
 #ifndef CGNN_STREAM_NO_EVN
+            if (ENC) {
 #pragma unroll
-            for (int o = 0; o < DO; ++o) ev[o] = ev_n[o];
+                for (int j = 0; j < 8; ++j) at[j] = at_n[j];
+            } else {
+#pragma unroll
+                for (int o = 0; o < DO; ++o) ev[o] = ev_n[o];
+            }
 #else       // (developer variant for smaller register budgets: the next tile's latents are fetched only now)
 #pragma unroll
             for (int o = 0; o < DO; ++o)
@@ -377,14 +456,16 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
 template <int HT, int DT>
 static int launch_stream(const StreamArgs& a, size_t lds, const __bf16* ps, const __bf16* pd, int64_t round_stride,
                          const int32_t* src, const int32_t* dst, int64_t num_edges, const float* e_in, float* e_out,
-                         hipStream_t st) {
+                         const float* attr, int ld_attr, hipStream_t st) {
     // P rows through the matrix pipe (measured 24.2 ms against 28.1 ms through the vector pipe at cfg3: the loop is
     // bound by vector issue).  CGNN_STREAM_PMFMA=0 selects the vector form (developer A/B).
     static const bool pmfma = [] {
         const char* v = getenv("CGNN_STREAM_PMFMA");
         return !(v && atoi(v) == 0);
     }();
-    auto kern = pmfma ? edge_stream_n16_kernel<HT, DT, true> : edge_stream_n16_kernel<HT, DT, false>;
+    const bool enc = a.enc_layers > 0;
+    auto kern = enc ? edge_stream_n16_kernel<HT, DT, true, true>
+                    : (pmfma ? edge_stream_n16_kernel<HT, DT, true, false> : edge_stream_n16_kernel<HT, DT, false, false>);
     if (lds > 48 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
@@ -392,7 +473,7 @@ static int launch_stream(const StreamArgs& a, size_t lds, const __bf16* ps, cons
         if (rc != CGNN_OK) return rc;
     }
     const int grid = grid_for_tiles((num_edges + 15) / 16, 1, CGNN_STREAM_WAVES);
-    kern<<<grid, CGNN_STREAM_BLOCK, lds, st>>>(a, ps, pd, round_stride, src, dst, num_edges, e_in, e_out);
+    kern<<<grid, CGNN_STREAM_BLOCK, lds, st>>>(a, ps, pd, round_stride, src, dst, num_edges, e_in, e_out, attr, ld_attr);
 #ifdef CGNN_STREAM_STAMPS
     {
         static int printed = 0;
@@ -417,9 +498,10 @@ using namespace cgnn;
 
 extern "C" int cgnn_edge_stream(const cgnn_mlp* rounds, int32_t num_rounds, const void* ps_all, const void* pd_all,
                                 int64_t round_stride, const int32_t* src, const int32_t* dst, int64_t num_edges,
-                                const float* e_in, float* e_out, int32_t latent, void* stream) {
-    if (!rounds || num_rounds < 1 || !ps_all || !pd_all || !src || !dst || !e_in || !e_out || num_edges < 0 ||
-        latent <= 0 || round_stride < 0) {
+                                const float* e_in, float* e_out, int32_t latent, const cgnn_mlp* encoder,
+                                const float* edge_attr, int32_t ld_attr, void* stream) {
+    if (!rounds || num_rounds < 1 || !ps_all || !pd_all || !src || !dst || !e_out || num_edges < 0 || latent <= 0 ||
+        round_stride < 0 || (encoder ? (!edge_attr || ld_attr <= 0) : !e_in)) {
         set_error("cgnn_edge_stream: invalid argument");
         return CGNN_ERR_INVALID_ARG;
     }
@@ -431,6 +513,39 @@ extern "C" int cgnn_edge_stream(const cgnn_mlp* rounds, int32_t num_rounds, cons
     memset(&a, 0, sizeof(a));
     a.rounds = num_rounds;
     int hidden = 0, nh = 0;
+    {
+        MlpDev m0;
+        int rc = make_mlp_dev(&rounds[0], &m0, nullptr, "cgnn_edge_stream");
+        if (rc != CGNN_OK) return rc;
+        hidden = m0.out_dim[0];
+        nh = m0.nh;
+    }
+    const int enc_n = encoder ? nh + 1 : 0;
+    if ((int64_t)num_rounds * (nh + 1) + enc_n > CGNN_STREAM_MAX_CHUNKS) {
+        set_error("cgnn_edge_stream: %d rounds x %d layers exceed %d ring entries", num_rounds, nh + 1,
+                  CGNN_STREAM_MAX_CHUNKS);
+        return CGNN_ERR_UNSUPPORTED;
+    }
+    if (encoder) {
+        MlpDev m;
+        int rc = make_mlp_dev(encoder, &m, nullptr, "cgnn_edge_stream(encoder)");
+        if (rc != CGNN_OK) return rc;
+        if (encoder->precision != CGNN_BF16_N16 || !m.gamma || m.nh != nh || m.in_dim[0] > 32 || ld_attr < m.in_dim[0] ||
+            m.out_dim[0] != hidden || m.out_dim[nh] != latent) {
+            set_error("cgnn_edge_stream: the encoder must be CGNN_BF16_N16 with LayerNorm, <= 32 inputs and the rounds' "
+                      "hidden / latent sizes and depth");
+            return CGNN_ERR_UNSUPPORTED;
+        }
+        for (int l = 0; l <= nh; ++l) {
+            a.w[l] = (const char*)m.w[l];
+            a.bias[l] = m.b[l];
+            a.chunk_bytes[l] = m.bytes[l];
+        }
+        a.enc_layers = enc_n;
+        a.enc_in_dim = m.in_dim[0];
+        a.enc_gamma = m.gamma;
+        a.enc_beta = m.beta;
+    }
     for (int r = 0; r < num_rounds; ++r) {
         MlpDev m;
         int rc = make_mlp_dev(&rounds[r], &m, nullptr, "cgnn_edge_stream");
@@ -438,15 +553,6 @@ extern "C" int cgnn_edge_stream(const cgnn_mlp* rounds, int32_t num_rounds, cons
         if (rounds[r].precision != CGNN_BF16_N16 || !m.gamma) {
             set_error("cgnn_edge_stream: round %d needs CGNN_BF16_N16 weights and LayerNorm parameters", r);
             return CGNN_ERR_UNSUPPORTED;
-        }
-        if (r == 0) {
-            hidden = m.out_dim[0];
-            nh = m.nh;
-            if ((int64_t)num_rounds * (nh + 1) > CGNN_STREAM_MAX_CHUNKS) {
-                set_error("cgnn_edge_stream: %d rounds x %d layers exceed %d ring entries", num_rounds, nh + 1,
-                          CGNN_STREAM_MAX_CHUNKS);
-                return CGNN_ERR_UNSUPPORTED;
-            }
         }
         if (m.nh != nh || m.in_dim[0] != latent || m.out_dim[0] != hidden || m.out_dim[nh] != latent ||
             m.in_dim[nh] != hidden) {
@@ -459,7 +565,7 @@ extern "C" int cgnn_edge_stream(const cgnn_mlp* rounds, int32_t num_rounds, cons
                 set_error("cgnn_edge_stream: round %d hidden layer %d has the wrong shape", r, l);
                 return CGNN_ERR_INVALID_ARG;
             }
-            const int ci = r * (nh + 1) + l;
+            const int ci = enc_n + r * (nh + 1) + l;
             a.w[ci] = (const char*)m.w[l];
             a.bias[ci] = m.b[l];
             a.chunk_bytes[ci] = m.bytes[l];
@@ -476,7 +582,8 @@ extern "C" int cgnn_edge_stream(const cgnn_mlp* rounds, int32_t num_rounds, cons
     const int HT = hidden / 32, DT = latent / 32;
     const int wmax = hidden > latent ? hidden : latent;
     const size_t slot = 2u * (size_t)hidden * wmax;
-    const size_t lds = CGNN_STREAM_SLOTS * slot + (size_t)num_rounds * (nh + 2) * wmax * 4 + 12 * CGNN_STREAM_MAX_CHUNKS;
+    const size_t lds = CGNN_STREAM_SLOTS * slot + ((size_t)num_rounds * (nh + 2) + (encoder ? nh + 3 : 0)) * wmax * 4 +
+                       12 * CGNN_STREAM_MAX_CHUNKS;
     if (lds > 160 * 1024) {
         set_error("cgnn_edge_stream: needs %zu bytes of LDS (three %zu-byte layer slots + %d rounds of vectors)", lds, slot,
                   num_rounds);
@@ -485,7 +592,7 @@ extern "C" int cgnn_edge_stream(const cgnn_mlp* rounds, int32_t num_rounds, cons
     hipStream_t st = (hipStream_t)stream;
 #define CGNN_STREAM(Hh, Dd)   \
     if (HT == Hh && DT == Dd) \
-        return launch_stream<Hh, Dd>(a, lds, (const __bf16*)ps_all, (const __bf16*)pd_all, round_stride, src, dst, num_edges, e_in, e_out, st);
+        return launch_stream<Hh, Dd>(a, lds, (const __bf16*)ps_all, (const __bf16*)pd_all, round_stride, src, dst, num_edges, e_in, e_out, edge_attr, ld_attr, st);
     CGNN_STREAM(1, 1) CGNN_STREAM(2, 2) CGNN_STREAM(4, 4)
 #undef CGNN_STREAM
     set_error("cgnn_edge_stream: no kernel for latent=%d hidden=%d (built for hidden == latent in {32,64,128})", latent,

@@ -264,7 +264,9 @@ class ShardedForward:
         ops.mlp_rows(P["enc_node"], sh.x_feat, out=self.x_all[:sh.n_owned])
         self._projected = False
         self._edges_pending = False
-        self.el = ops.mlp_rows(P["enc_edge"], sh.edge_attr, tiled=True)
+        # fused mode: the edge encoder runs inside cgnn_edge_stream when it has the rounds' shape
+        self._enc_in_stream = self.fused and m._encoder_fits_stream(P)
+        self.el = None if self._enc_in_stream else ops.mlp_rows(P["enc_edge"], sh.edge_attr, tiled=True)
         self.e_upd = self.el.empty_like() if m.message_source == "edge" else None
 
     def round(self, i: int):
@@ -333,8 +335,9 @@ class ShardedForward:
         """Fused mode: all edge updates in one launch, once the last round's node half has run."""
         if self.fused and self._edges_pending:
             sh = self.sh
-            ops.edge_stream([p.edge for p in self.P["rounds"]], self.ps, self.pd, sh.src_local, sh.dst_local, self.el,
-                            self.el)
+            enc = self.P["enc_edge"] if self._enc_in_stream else None
+            self.el = ops.edge_stream([p.edge for p in self.P["rounds"]], self.ps, self.pd, sh.src_local, sh.dst_local,
+                                      self.el, self.el, enc, sh.edge_attr if enc is not None else None)
             self._edges_pending = False
 
     def decode(self) -> dict:

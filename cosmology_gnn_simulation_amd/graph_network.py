@@ -287,7 +287,8 @@ def _run_round(p: _PackedProcessor, x: torch.Tensor, e: torch.Tensor, src, dst, 
     return x_new, e_new, nxt is not None
 
 
-def _run_rounds_fused(rounds, x: torch.Tensor, e, src, dst, fixed_k: int, agg: Optional[torch.Tensor]):
+def _run_rounds_fused(rounds, x: torch.Tensor, e, src, dst, fixed_k: int, agg: Optional[torch.Tensor],
+                      encoder=None, edge_attr: Optional[torch.Tensor] = None):
     """All residual rounds under the reference's data flow (aggregation of sender NODE latents): the node
     stream does not read the edge stream, so it runs first and leaves every round's Ps / Pd tables behind (the node
     kernel's epilogue writes round i+1's); then one launch applies all edge updates while each edge tile stays in
@@ -306,7 +307,9 @@ def _run_rounds_fused(rounds, x: torch.Tensor, e, src, dst, fixed_k: int, agg: O
             fused_ok = p.node.precision == _lib.F32X3_N16 and q.ws_fused.precision == _lib.BF16_N16
             nxt = (q.ws_fused if fused_ok else q.ws, q.wd_fused if fused_ok else q.wd, ps_all[i + 1], pd_all[i + 1], fmt)
         x = ops.node_block(p.node, p.wx, p.wa, x, agg, x, True, nxt)
-    e = ops.edge_stream([p.edge for p in rounds], ps_all, pd_all, src, dst, e, e)
+    # `encoder` (the packed edge encoder) given: the initial edge latents are computed inside the same launch and
+    # never written to memory (e is None then)
+    e = ops.edge_stream([p.edge for p in rounds], ps_all, pd_all, src, dst, e, e, encoder, edge_attr)
     return x, e
 
 
@@ -439,6 +442,19 @@ class EncodeProcessDecode(nn.Module):
             p.edge.precision == _lib.BF16_N16 and p.p_format == _lib.P_BF16_S16 and p.edge.hidden == latent and
             p.edge.num_hidden_layers == nh for p in rounds)
 
+    def _encoder_fits_stream(self, P) -> bool:
+        """The edge encoder can run inside ``cgnn_edge_stream`` (16-edge bf16 packing, same depth and widths as the
+        rounds' edge models, LDS room for its vectors)."""
+        rounds, enc = P["rounds"], P["enc_edge"]
+        if not rounds or enc.precision != _lib.BF16_N16:
+            return False
+        e0 = rounds[0].edge
+        latent = e0.out_dim
+        lds = 3 * 2 * latent * latent + (len(rounds) * (e0.num_hidden_layers + 2) + e0.num_hidden_layers + 3) * latent * 4 \
+            + 12 * 64
+        return (enc.num_hidden_layers == e0.num_hidden_layers and enc.hidden == e0.hidden and enc.out_dim == latent and
+                enc.in_dim <= 32 and (len(rounds) + 1) * (e0.num_hidden_layers + 1) <= 64 and lds <= 160 * 1024)
+
     # -- forward ---------------------------------------------------------------
     def forward(self, input_graph) -> dict:
         out = self._forward(input_graph, want_latents=False)
@@ -518,7 +534,10 @@ class EncodeProcessDecode(nn.Module):
                 edge_attr = ops.gather_rows(edge_attr.view(n, -1), order).view(n * fixed_k, -1)
             P = self._pack(x.shape[1], edge_attr.shape[1])
             xl = ops.mlp_rows(P["enc_node"], x)
-            el = ops.mlp_rows(P["enc_edge"], edge_attr, tiled=True)      # edge latents live in TILED32 layout
+            fuse = self._can_fuse_rounds(P["rounds"], xl.shape[1])
+            enc_in_stream = fuse and self._encoder_fits_stream(P)
+            # edge latents live in TILED32 layout; in the fused path the encoder runs inside cgnn_edge_stream
+            el = None if enc_in_stream else ops.mlp_rows(P["enc_edge"], edge_attr, tiled=True)
             H = P["rounds"][0].ws.out_dim if P["rounds"] else 0
             scratch = None
             if P["rounds"]:
@@ -527,12 +546,13 @@ class EncodeProcessDecode(nn.Module):
                 ps = torch.empty((n, H), dtype=pdt, device=dev)
                 pd = torch.empty((n, H), dtype=pdt, device=dev)
                 agg = torch.empty((n, xl.shape[1]), dtype=torch.float32, device=dev)
-                e_upd = el.empty_like() if self.message_source == "edge" else None
+                e_upd = el.empty_like() if (self.message_source == "edge" and el is not None) else None
                 scratch = (ps, pd, agg, e_upd)
             projected = False
             rounds = P["rounds"]
-            if self._can_fuse_rounds(rounds, xl.shape[1]):
-                xl, el = _run_rounds_fused(rounds, xl, el, src, dst, fixed_k, agg)
+            if fuse:
+                xl, el = _run_rounds_fused(rounds, xl, el, src, dst, fixed_k, agg,
+                                           P["enc_edge"] if enc_in_stream else None, edge_attr)
                 rounds = []
             for i, p in enumerate(rounds):
                 # residual streams updated in place (reference graph_network.py:181-182); the node kernel also

@@ -272,30 +272,47 @@ def edge_block(mlp: PackedMLP, ps: torch.Tensor, pd: torch.Tensor, src: torch.Te
 
 
 def edge_stream(mlps: Sequence[PackedMLP], ps_all: torch.Tensor, pd_all: torch.Tensor, src: torch.Tensor,
-                dst: torch.Tensor, e_in: TiledRows, e_out: Optional[TiledRows] = None) -> TiledRows:
+                dst: torch.Tensor, e_in: Optional[TiledRows], e_out: Optional[TiledRows] = None,
+                encoder: Optional[PackedMLP] = None, edge_attr: Optional[torch.Tensor] = None) -> TiledRows:
     """All ``len(mlps)`` residual edge updates in one launch (``cgnn_edge_stream``; reference-faithful message only:
     the caller has already computed every round's ``Ps`` / ``Pd``).  ``ps_all`` / ``pd_all``: ``[rounds, N, H]`` bf16
-    tables in the 16-edge kernel's format."""
-    if not isinstance(e_in, TiledRows):
-        raise CgnnError("edge_stream: edge latents must be TiledRows")
+    tables in the 16-edge kernel's format.  With ``encoder`` (the packed edge encoder) and ``edge_attr`` the initial
+    latents are computed in the same launch instead of being read from ``e_in``."""
     src, dst = i32c(src, "src"), i32c(dst, "dst")
-    ne, latent = e_in.n, e_in.width
     rounds = len(mlps)
-    if e_out is None:
-        e_out = e_in.empty_like()
+    ne = src.numel()
+    if encoder is not None:
+        if edge_attr is None:
+            raise CgnnError("edge_stream: the encoder needs edge_attr")
+        edge_attr = f32c(edge_attr, "edge_attr")
+        if edge_attr.shape != (ne, encoder.in_dim) or encoder.precision != BF16_N16:
+            raise CgnnError("edge_stream: edge_attr must be [E, encoder fan-in] and the encoder packed 'bf16_n16'")
+        latent = encoder.out_dim
+        if e_out is None:
+            e_out = TiledRows(ne, latent, src.device)
+    else:
+        if not isinstance(e_in, TiledRows):
+            raise CgnnError("edge_stream: edge latents must be TiledRows")
+        latent = e_in.width
+        if e_out is None:
+            e_out = e_in.empty_like()
     for t, name in ((ps_all, "ps_all"), (pd_all, "pd_all")):
         require_device(t, name)
         if t.dtype != torch.bfloat16 or not t.is_contiguous() or t.dim() != 3 or t.shape[0] != rounds:
             raise CgnnError(f"edge_stream: {name} must be a contiguous bfloat16 [rounds, N, H] table")
     if any(m.precision != BF16_N16 for m in mlps):
         raise CgnnError("edge_stream: the edge models must be packed 'bf16_n16'")
-    if src.numel() != ne or dst.numel() != ne or e_out.n != ne or e_out.width != latent:
+    if dst.numel() != ne or e_out.n != ne or e_out.width != latent or (e_in is not None and e_in.n != ne):
         raise CgnnError("edge_stream: src/dst/e_out do not match the edge latents")
     arr = (Mlp * rounds)(*[m.struct() for m in mlps])
-    with _timed("edge_stream", e_in.device):
+    enc = encoder.struct() if encoder is not None else None
+    with _timed("edge_stream", src.device):
         check(_lib.load().cgnn_edge_stream(arr, rounds, ps_all.data_ptr(), pd_all.data_ptr(),
-                                           ps_all.stride(0), src.data_ptr(), dst.data_ptr(), ne, e_in.buf.data_ptr(),
-                                           e_out.buf.data_ptr(), latent, stream_ptr(e_in.device)), "cgnn_edge_stream")
+                                           ps_all.stride(0), src.data_ptr(), dst.data_ptr(), ne,
+                                           e_in.buf.data_ptr() if e_in is not None else None, e_out.buf.data_ptr(), latent,
+                                           C.byref(enc) if enc is not None else None, ptr(edge_attr),
+                                           edge_attr.stride(0) if edge_attr is not None else 0,
+                                           stream_ptr(src.device)), "cgnn_edge_stream")
     return e_out
 
 

@@ -193,10 +193,14 @@ int cgnn_node_block(const cgnn_mlp* mlp, const cgnn_linear* w_x, const cgnn_line
  *   rounds[r]       edge model of round r, CGNN_BF16_N16, layer[0] = the We column block (as for cgnn_edge_block)
  *   ps_all, pd_all  CGNN_P_BF16_S16 tables of all rounds; round r starts at element r * round_stride
  *   e_in, e_out     CGNN_TILED32 edge latents (may be the same buffer)
+ *   encoder         optional (NULL: start from e_in): the edge encoder of graph_network.py:57 (CGNN_BF16_N16, <= 32
+ *                   inputs, LayerNorm), run on each tile's rows of edge_attr [E, ld_attr] before round 0, so that its
+ *                   E x latent output is never written to memory; e_in is then ignored
  * Built for hidden == latent in {32, 64, 128}. */
 int cgnn_edge_stream(const cgnn_mlp* rounds, int32_t num_rounds, const void* ps_all, const void* pd_all,
                      int64_t round_stride, const int32_t* src, const int32_t* dst, int64_t num_edges,
-                     const float* e_in, float* e_out, int32_t latent, void* stream);
+                     const float* e_in, float* e_out, int32_t latent, const cgnn_mlp* encoder, const float* edge_attr,
+                     int32_t ld_attr, void* stream);
 
 /* ---- backward of a row-wise MLP (+LayerNorm): the node stream of train.py:263 ------------------------
  * In reference-faithful mode only the node path carries gradient (the edge models' parameters get

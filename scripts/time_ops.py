@@ -72,6 +72,11 @@ if a.edge_precision == "bf16" and (not a.only or a.only == "edge_stream"):
     pd_all = torch.randn(L, n, d, device=dev).to(torch.bfloat16)
     t("edge_stream", lambda: ops.edge_stream([r.edge for r in roundsL], ps_all, pd_all, src, dst, e, e),
       2 * E * d * 4 + 2 * E * 4 + L * 2 * n * d * 2, L * 6.0 * E * d * d)
+    PL_ = mL._pack(17, 4)
+    if mL._encoder_fits_stream(PL_):
+        t("edge_stream+enc", lambda: ops.edge_stream([r.edge for r in roundsL], ps_all, pd_all, src, dst, None, e,
+                                                     PL_["enc_edge"], ea),
+          E * d * 4 + E * 16 + 2 * E * 4 + L * 2 * n * d * 2, L * 6.0 * E * d * d + 2.0 * E * (32 * d + 2 * d * d))
 t("edge_block", lambda: ops.edge_block(p.edge, ps, pd, src, dst, e, e, None, True),
   2 * E * d * 4 + 2 * E * 4 + 2 * n * d * 4, 6.0 * E * d * d)
 t("aggregate x_j", lambda: ops.aggregate(x, src, dst, n, fk, E, agg), E * d * 4 + E * 4 + n * d * 4)
