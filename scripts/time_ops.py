@@ -67,7 +67,7 @@ mL.load_state_dict(synthetic.make_state_dict(d, d, 2, L, 3))
 mL = mL.to(dev).eval()
 mL.edge_precision, mL.node_precision = a.edge_precision, a.node_precision
 roundsL = mL._pack(17, 4)["rounds"]
-if a.edge_precision == "bf16" and (not a.only or a.only == "edge_stream"):
+if a.edge_precision == "bf16" and (not a.only or a.only.startswith("edge_stream")):
     ps_all = torch.randn(L, n, d, device=dev).to(torch.bfloat16)
     pd_all = torch.randn(L, n, d, device=dev).to(torch.bfloat16)
     t("edge_stream", lambda: ops.edge_stream([r.edge for r in roundsL], ps_all, pd_all, src, dst, e, e),
