@@ -16,6 +16,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The C-ABI library is a build artefact (git-ignored): build it once if a fresh checkout has none (hipcc
+    cross-compiles gfx950 without a GPU; about a minute)."""
+    lib = os.path.join(ROOT, "cosmology_gnn_simulation_amd", "libcgnn_hip.so")
+    if not os.path.isfile(lib):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
     g = {k: z[k] for k in z.files}
