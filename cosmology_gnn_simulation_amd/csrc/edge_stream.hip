@@ -5,7 +5,8 @@
 // reads the edge stream, so the per-node halves Ps_r / Pd_r of every round's first edge Linear are known before any
 // edge is touched.  An edge's latent tile can then stay in registers through all L updates
 //     e <- e + LN_r(MLP_r(Ps_r[src] + Pd_r[dst] + We_r e))          r = 0 .. L-1
-// and the E x D f32 stream crosses HBM once instead of L times (cfg3: 16 GB instead of 164 GB).  What no longer
+// and the E x D f32 stream crosses HBM once instead of L times; with the edge encoder run on the tile in the same launch
+// (ENC) it is only ever written (cfg3, PMC: 16 GB of HBM traffic instead of 182 GB).  What no longer
 // fits is the weights: one round's three 128x128 bf16 layers fill the LDS, so the layers of all rounds cycle through
 // a three-slot LDS ring, copied by LDS-DMA two layers ahead of their use; the eight waves of a workgroup meet at one
 // barrier per layer.  Arithmetic (MFMA shapes, operand order, f32 LayerNorm and residual) is that of
