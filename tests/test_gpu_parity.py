@@ -449,6 +449,33 @@ def test_all_rounds_in_one_launch_is_bitwise_equivalent(n, k, latent, nh, steps)
     assert "edge_stream" not in tm.summary()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_all_rounds_in_one_launch_random_shapes(seed):
+    """Randomised shapes for cgnn_edge_stream (tile counts below, at and above the grid's wave count, odd numbers of
+    16-edge tiles, 1..12 rounds, 1..3 hidden layers): bit-identical to one launch per round."""
+    rng = np.random.default_rng(1000 + seed)
+    latent = int(rng.choice([32, 64, 128]))
+    k = int(rng.choice([8, 16]))
+    n = int(rng.choice([int(rng.integers(k + 1, 200)), int(rng.integers(200, 6000)), int(rng.integers(30000, 70000))]))
+    nh = int(rng.integers(1, 4))
+    steps = int(rng.integers(1, 13))
+    snap = synthetic.make_snapshot(n, seed=seed)
+    meta = synthetic.make_metadata()
+    d = data_utils.preprocess(snap["Coordinates"][:W], snap["InternalEnergy"][:W], meta, None, None, 0.0, k, 0.01, 1.0)
+    m = graph_network.EncodeProcessDecode(latent, latent, nh, steps, 3)
+    m.load_state_dict(synthetic.make_state_dict(latent, latent, nh, steps, 3, seed=seed + 3))
+    m = m.to(DEV).eval()
+    m.edge_precision, m.node_precision = "bf16", "fp32x3"
+    with ops.OpTimer() as tm, torch.no_grad():
+        a = m.forward_with_latents(d)
+    assert "edge_stream" in tm.summary(), (latent, k, n, nh, steps)
+    m.fuse_rounds = False
+    with torch.no_grad():
+        b = m.forward_with_latents(d)
+    for key in ("acceleration", "temp_rate", "x_latent", "edge_latent"):
+        assert torch.equal(a[key], b[key]), (key, latent, k, n, nh, steps)
+
+
 def test_edge_stream_rejects_what_it_cannot_run():
     d, n, k = 64, 64, 8
     m = graph_network.EncodeProcessDecode(d, d, 2, 2, 3)
