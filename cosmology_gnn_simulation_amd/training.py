@@ -8,7 +8,7 @@ stream never reaches the outputs.  The autograd graph from the loss 
     acceleration = dec_acc(x_L),  temp_rate = dec_tr(x_L)
 
 and every edge-model parameter keeps ``grad = None`` under the reference as well.  This module runs exactly that
-graph in exact f32: the training forward skips the (dead) edge stream, keeps ``x_i`` per round, and the backward
+graph in exact f32: the training forward skips the (dead) edge stream, keeps ``x_i`` and ``agg_i`` per round, and the backward
 recomputes the activations tile by tile (``cgnn_mlp_backward``), transposes the aggregation by gathering through
 the sender-major adjacency (``cgnn_csr_build`` once per graph, ``cgnn_aggregate_csr``) and reduces the parameter
 gradients with ``cgnn_weight_grad`` / ``cgnn_col_dot``.
@@ -122,13 +122,15 @@ class _NodeStream(torch.autograd.Function):
         src, dst, fixed_k, _ = graph
         n = x0.shape[0]
         xs = [ops.mlp_rows(packs.enc.fwd, x0)]
+        aggs = []                   # kept for the backward (N x D x 4 bytes per round; recomputing them cost 6 % of a step)
         for r in packs.rounds:
             x = xs[-1]
             agg = ops.aggregate(x, src, dst, n, fixed_k, src.numel())
+            aggs.append(agg)
             xs.append(ops.node_block(r.fwd, r.fwd.layers[0], r.fwd2, x, agg, None, residual=True))
         acc = ops.mlp_rows(packs.dec_acc.fwd, xs[-1])
         tr = ops.mlp_rows(packs.dec_tr.fwd, xs[-1])
-        ctx.packs, ctx.graph, ctx.x0, ctx.xs = packs, graph, x0, xs
+        ctx.packs, ctx.graph, ctx.x0, ctx.xs, ctx.aggs = packs, graph, x0, xs, aggs
         return acc, tr
 
     @staticmethod
@@ -147,7 +149,8 @@ class _NodeStream(torch.autograd.Function):
         dx = dx.add_(dx2)
         for i in range(len(packs.rounds) - 1, -1, -1):
             r, x = packs.rounds[i], xs[i]
-            agg = ops.aggregate(x, src, dst, n, fixed_k, src.numel())          # recomputed, not kept
+            agg = ctx.aggs[i]
+            ctx.aggs[i] = None
             du1, du2, grads_of[id(r)] = r.backward(x, agg, dx, scratch, True, True)
             # x_{i+1} = x_i + f(x_i, agg(x_i)):  dx_i = dx_{i+1} + du1 + A^T du2     (A^T: senders <- receivers)
             dagg = ops.aggregate_csr(du2, by_sender)
