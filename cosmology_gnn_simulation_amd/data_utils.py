@@ -107,7 +107,7 @@ def _draw_reference_noise(pos_seq: torch.Tensor, tmp_seq: torch.Tensor, noise_st
 
 def preprocess(position_seq, temperature_seq, metadata, target_position=None, target_temperature=None,
                noise_std=0.0, num_neighbors=16, dt=None, box_size=None, device: Optional[torch.device] = None,
-               reference_rng: bool = True):
+               reference_rng: bool = True, check_bounds: bool = True):
     """Window ``[W, N, 3]`` / ``[W, N, 1]`` -> graph (reference data_utils.py:72-228).
 
     ``device`` (extension) selects the GPU; by default the inputs' device if they
@@ -115,7 +115,8 @@ def preprocess(position_seq, temperature_seq, metadata, target_position=None, ta
     there, so the caller's ``graph.to(device)`` is a no-op.  ``reference_rng=False``
     (extension, only honoured when ``noise_std == 0``) skips the two CPU random draws
     the reference makes even for zero noise; results are identical, only the global
-    RNG stream is left untouched (used by the on-device rollout)."""
+    RNG stream is left untouched (used by the on-device rollout).  ``check_bounds=False`` (extension) drops the
+    reference's sender-index assertion (:158-159), which costs one device-to-host synchronisation per call."""
     dt = float(dt)
     box_size = float(box_size)
     if device is None:
@@ -166,7 +167,8 @@ def preprocess(position_seq, temperature_seq, metadata, target_position=None, ta
     edge_index, edge_attr, senders, order = knn_graph_periodic(recent_position, box_size, int(num_neighbors),
                                                                 want_order=True)
     n = recent_position.shape[0]
-    assert int(senders.max()) < n, f"Max sender index {int(senders.max())} >= {n}"
+    if check_bounds:    # reference :158-159 (a host round trip: the on-device rollout turns it off)
+        assert int(senders.max()) < n, f"Max sender index {int(senders.max())} >= {n}"
 
     acceleration = None
     temp_rate = None

@@ -21,7 +21,10 @@ def rollout(model, data: Dict[str, torch.Tensor], metadata: dict, noise_std: flo
             window_size: int = 6, num_neighbors: int = 16, num_steps: Optional[int] = None,
             device: Optional[torch.device] = None, reference_rng: bool = False) -> Dict[str, torch.Tensor]:
     """Same arguments and return value as the reference (``Coordinates [T, N, 3]``,
-    ``InternalEnergy [T, N, 1]``, the first ``window_size`` frames copied from ``data``)."""
+    ``InternalEnergy [T, N, 1]``, the first ``window_size`` frames copied from ``data``).  ``noise_std`` is
+    accepted for signature compatibility only: the reference builds every rollout graph with ``noise_std=0.0``
+    whatever the argument says (render_rollout.py:44-52, "Build a graph with no noise for rollout")."""
+    del noise_std
     if device is None:
         device = next(model.parameters()).device
     device = torch.device(device)
@@ -42,9 +45,9 @@ def rollout(model, data: Dict[str, torch.Tensor], metadata: dict, noise_std: flo
         for t in range(window_size, total_time):
             win_p = pos_traj[t - window_size:t]                      # [W, N, 3] views, no copies
             win_t = tmp_traj[t - window_size:t]
-            graph = preprocess(position_seq=win_p, temperature_seq=win_t, metadata=meta, noise_std=noise_std,
+            graph = preprocess(position_seq=win_p, temperature_seq=win_t, metadata=meta, noise_std=0.0,
                                num_neighbors=num_neighbors, box_size=box_size, dt=dt, device=device,
-                               reference_rng=reference_rng)
+                               reference_rng=reference_rng, check_bounds=False)
             pred = model(graph)
             new_p, new_t = integrate_one_step(pred["acceleration"], pred["temp_rate"], win_p, win_t, meta)
             pos_traj[t] = new_p

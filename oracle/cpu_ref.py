@@ -17,7 +17,7 @@ What it restates (all citations are into the read-only reference checkout):
 * ``data_utils.py:72-228``     preprocess           -> :func:`preprocess`
 * ``one_step_test.py:84-111``  one-step integrator  -> :func:`one_step`
 * ``train.py:107-118``         momentum term        -> :func:`momentum_conservation_loss`
-* ``render_rollout.py:26-90``  autoregressive rollout -> :func:`rollout` (restatement only, no reference fixture)
+* ``render_rollout.py:26-90``  autoregressive rollout -> :func:`rollout`
 
 Third-party arithmetic that is NOT in the reference checkout and is restated
 here from its published behaviour:
@@ -37,8 +37,11 @@ Pinning status: the reference ships no tests, fixtures or golden vectors.  The
 restatement is pinned against outputs of the reference's own source lines run in
 the build container behind stand-ins for the two absent packages
 (``oracle/reference_shim.py`` + ``oracle/make_golden.py`` ->
-``tests/golden/*.npz``).  The semantics of the stand-ins themselves (the two
-bullets above) are unpinned.
+``tests/golden/*.npz``); the driver-level functions (``validate_one_step``,
+``momentum_conservation_loss``, ``rollout``) are pinned the same way by
+``tests/golden/harness.npz`` (reference drivers run behind an in-memory ``h5py.File``
+stand-in).  The semantics of the stand-ins themselves (the two bullets above) are
+unpinned.
 """
 from __future__ import annotations
 
@@ -353,8 +356,9 @@ def momentum_conservation_loss(accelerations: Tensor, batch: Tensor, num_graphs:
 
 def rollout(sd: StateDict, nh: int, steps: int, coords: Tensor, energy: Tensor, metadata: dict, window_size: int,
             num_neighbors: int, total_time: int) -> dict:
-    """render_rollout.py:26-90 restated (restatement only: that module imports h5py / matplotlib at import time
-    and cannot be loaded here, so this function has no reference-produced fixture)."""
+    """render_rollout.py:26-90 restated (the reference always builds the graph with ``noise_std=0.0`` and grows the
+    trajectory by ``cat``; ``num_neighbors`` is hard-coded 16 there).  Pinned by ``tests/golden/harness.npz``:
+    the reference's own ``rollout`` run behind the h5py stand-in, bit-identical trajectory."""
     dt, box = metadata["dt"], metadata["box_size"]
     pos = [coords[i].float() for i in range(window_size)]
     tmp = [energy[i].float() for i in range(window_size)]

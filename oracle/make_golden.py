@@ -112,11 +112,112 @@ def run_case(name: str, c: dict) -> None:
     print("wrote", path, f"{os.path.getsize(path) / 1e6:.2f} MB")
 
 
+HARNESS_META = dict(vel_mean=0.02, vel_std=1.3, acc_mean=0.01, acc_std=0.7, temp_mean=1.0, temp_std=0.5,
+                    temp_rate_mean=-0.1, temp_rate_std=2.0, dt=0.01, box_size=1.0)
+
+
+def run_harness() -> None:
+    """``tests/golden/harness.npz``: outputs of the reference's own DRIVER functions -- ``validate_one_step``
+    (one_step_test.py:26-124), ``momentum_conservation_loss`` (validation.py:5-16 = train.py:107-118) on a ragged
+    three-graph batch, and ``rollout`` (render_rollout.py:26-90) -- run behind the h5py / Batch stand-ins of
+    ``oracle/reference_shim.py``; the restatement must reproduce each before the fixture is written."""
+    ost, val, rr = reference_shim.load_drivers()
+    gn, du = reference_shim.load()
+    n, k, d, nh, steps, T = 256, 16, 32, 2, 2, 12
+    meta = dict(HARNESS_META)
+    snap = synthetic.make_snapshot(n, window=T - 1, box_size=meta["box_size"], dt=meta["dt"], seed=4321)
+    coords, energy = snap["Coordinates"], snap["InternalEnergy"]
+
+    def ref_model(sd):
+        m = gn.EncodeProcessDecode(latent_size=d, mlp_hidden_size=d, mlp_num_hidden_layers=nh,
+                                   num_message_passing_steps=steps, output_size=3)
+        m.load_state_dict(sd)
+        return m.eval()
+
+    # ---- one_step_test.validate_one_step: its own window slicing, start-index draw, integration and MSEs -----------
+    W1 = 5
+    sd1 = synthetic.make_state_dict(d, d, nh, steps, 3, seed=11)
+    reference_shim.register_h5("mem://harness.hdf5", {"Coordinates": coords.numpy(), "InternalEnergy": energy.numpy()})
+    np.random.seed(2024)
+    torch.manual_seed(0)
+    res = ost.validate_one_step(ref_model(sd1), "mem://harness.hdf5", meta, W1, "cpu", num_neighbors=k, num_timesteps=3,
+                                noise_std=0.0)
+    starts = [t - W1 for t in res["tested_timesteps"]]
+    for s_, pe, te in zip(starts, res["position_errors"], res["temperature_errors"]):
+        g = cpu_ref.preprocess(coords[s_:s_ + W1].clone(), energy[s_:s_ + W1].clone(), meta, None, None, 0.0, k,
+                               meta["dt"], meta["box_size"])
+        with torch.no_grad():
+            o = cpu_ref.encode_process_decode(sd1, g["x"], g["edge_index"], g["edge_attr"], nh, steps)
+        st = cpu_ref.one_step(o["acceleration"], o["temp_rate"], coords[s_:s_ + W1], energy[s_:s_ + W1], coords[s_ + W1],
+                              energy[s_ + W1], meta)
+        assert abs(st["position_mse"] - pe) <= 1e-6 * abs(pe), (st["position_mse"], pe)
+        assert abs(st["temperature_mse"] - te) <= 1e-6 * abs(te), (st["temperature_mse"], te)
+
+    # ---- validation.momentum_conservation_loss on a ragged batch of three graphs ------------------------------------
+    sizes, kb = (100, 57, 131), 8
+    graphs, wins = [], []
+    for i, m_ in enumerate(sizes):
+        sn = synthetic.make_snapshot(m_, window=W1, box_size=meta["box_size"], dt=meta["dt"], seed=900 + i)
+        wins.append((sn["Coordinates"], sn["InternalEnergy"]))
+        graphs.append(du.preprocess(position_seq=sn["Coordinates"][:W1].clone(), temperature_seq=sn["InternalEnergy"][:W1].clone(),
+                                    metadata=meta, target_position=sn["Coordinates"][W1].clone(),
+                                    target_temperature=sn["InternalEnergy"][W1].clone(), noise_std=0.0, num_neighbors=kb,
+                                    dt=meta["dt"], box_size=meta["box_size"]))
+    import torch_geometric as pyg      # the stand-in module the reference's validation.py imported
+    batch = pyg.data.Batch.from_data_list(graphs)
+    with torch.no_grad():
+        bacc = ref_model(sd1)(batch)["acceleration"]
+    mom_w = 0.5
+    mom = float(val.momentum_conservation_loss(bacc, batch, meta["dt"], mom_w))
+    m2 = float(cpu_ref.momentum_conservation_loss(bacc, batch.batch, batch.num_graphs, meta["dt"], mom_w))
+    assert abs(m2 - mom) <= 1e-6 * abs(mom), (m2, mom)
+    with torch.no_grad():
+        o = cpu_ref.encode_process_decode(sd1, batch.x, batch.edge_index, batch.edge_attr, nh, steps)
+    assert rel(o["acceleration"], bacc) <= 1e-6
+
+    # ---- render_rollout.rollout: three autoregressive steps (window 6, its hard-coded 16 neighbours) ---------------
+    W2, R = 6, 3
+    sd2 = synthetic.make_state_dict(d, d, nh, steps, 3, node_in=3 * (W2 - 1) + W2, seed=12)
+    data = {"Coordinates": coords[:W2 + R].clone(), "InternalEnergy": energy[:W2 + R].clone()}
+    traj = rr.rollout(ref_model(sd2), data, meta, 0.0, meta["dt"], meta["box_size"], window_size=W2)
+    want = cpu_ref.rollout(sd2, nh, steps, coords, energy, meta, W2, 16, W2 + R)
+    assert traj["Coordinates"].shape == (W2 + R, n, 3)
+    assert torch.equal(want["Coordinates"], traj["Coordinates"]) and torch.equal(want["InternalEnergy"], traj["InternalEnergy"])
+
+    out = dict(n=n, k=k, latent=d, nh=nh, steps=steps, frames=T, coords=coords.numpy(), energy=energy.numpy(),
+               one_step_window=W1, one_step_tested=np.asarray(res["tested_timesteps"], dtype=np.int64),
+               one_step_position_errors=np.asarray(res["position_errors"], dtype=np.float64),
+               one_step_temperature_errors=np.asarray(res["temperature_errors"], dtype=np.float64),
+               one_step_position_error=np.float64(res["position_error"]),
+               one_step_temperature_error=np.float64(res["temperature_error"]),
+               batch_sizes=np.asarray(sizes, dtype=np.int64), batch_k=kb, momentum_weight=mom_w,
+               batch_acceleration=bacc.numpy(), batch_momentum=np.float64(mom),
+               rollout_window=W2, rollout_steps=R,
+               rollout_coords=traj["Coordinates"].numpy(), rollout_energy=traj["InternalEnergy"].numpy())
+    for i, (c_, e_) in enumerate(wins):
+        out[f"batch_coords{i}"] = c_.numpy()
+        out[f"batch_energy{i}"] = e_.numpy()
+    for key, v in meta.items():
+        out["meta:" + key] = np.float64(v)
+    for k_, v in sd1.items():
+        out["w1:" + k_] = v.numpy()
+    for k_, v in sd2.items():
+        out["w2:" + k_] = v.numpy()
+    path = os.path.join(GOLDEN, "harness.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, f"{os.path.getsize(path) / 1e6:.2f} MB; one-step frames", res["tested_timesteps"],
+          "momentum", mom)
+
+
 def main() -> None:
     if not reference_shim.available():
         raise SystemExit("reference checkout not present: fixtures can only be regenerated in the build container")
+    only = sys.argv[1:]
     for name, c in CASES.items():
-        run_case(name, c)
+        if not only or name in only:
+            run_case(name, c)
+    if not only or "harness" in only:
+        run_harness()
 
 
 if __name__ == "__main__":

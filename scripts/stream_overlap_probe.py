@@ -1,5 +1,5 @@
 """Developer experiment: do the node kernel and the aggregation kernel overlap when launched on two HIP streams?
-    python scripts/overlap_test.py"""
+    python scripts/stream_overlap_probe.py"""
 import os
 import sys
 import time

@@ -37,6 +37,22 @@ def load_golden(name):
     return g
 
 
+def load_harness():
+    """tests/golden/harness.npz: outputs of the reference's own driver functions (validate_one_step,
+    momentum_conservation_loss on a ragged batch, rollout), see oracle/make_golden.py::run_harness."""
+    z = np.load(os.path.join(GOLDEN_DIR, "harness.npz"))
+    g = {k: z[k] for k in z.files if not k.startswith(("w1:", "w2:", "meta:"))}
+    g["state_dict_one_step"] = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w1:")}
+    g["state_dict_rollout"] = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w2:")}
+    g["metadata"] = {k[5:]: float(z[k]) for k in z.files if k.startswith("meta:")}
+    return g
+
+
+@pytest.fixture(scope="session")
+def harness():
+    return load_harness()
+
+
 @pytest.fixture(scope="session", params=["tiny", "tiny_k16_box25", "cfg1"])
 def golden(request):
     return load_golden(request.param)

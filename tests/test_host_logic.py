@@ -101,3 +101,30 @@ def test_snapshot_io_and_metadata(tmp_path):
     assert abs(meta["temp_std"][0] - e.std(axis=(0, 1))[0]) < 1e-12
     with pytest.raises(ValueError):
         snapshot_io.read_snapshot(str(tmp_path / "x.bin"))
+
+
+def test_reference_module_names_resolve_to_the_engine(tmp_path):
+    """``from graph_network import EncodeProcessDecode`` / ``from data_utils import preprocess`` (reference
+    train.py:15-16, one_step_test.py:9-10) with ``compat/`` on PYTHONPATH; ``torch_geometric`` names with
+    ``compat/pyg_free`` as well.  Run in a child interpreter so this process's modules stay untouched."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import graph_network, data_utils, inspect\n"
+        "import cosmology_gnn_simulation_amd.graph_network as eng, cosmology_gnn_simulation_amd.data_utils as du\n"
+        "assert graph_network.EncodeProcessDecode is eng.EncodeProcessDecode\n"
+        "assert graph_network.InteractionNetwork is eng.InteractionNetwork and graph_network.build_mlp is eng.build_mlp\n"
+        "assert data_utils.preprocess is du.preprocess and data_utils.extend_positions_torch is du.extend_positions_torch\n"
+        "p = list(inspect.signature(data_utils.preprocess).parameters)[:9]\n"
+        "assert p == ['position_seq', 'temperature_seq', 'metadata', 'target_position', 'target_temperature',\n"
+        "             'noise_std', 'num_neighbors', 'dt', 'box_size'], p\n"
+        "import torch_geometric as pyg\n"
+        "from torch_geometric.loader import DataLoader\n"
+        "from cosmology_gnn_simulation_amd.graph import Batch\n"
+        "assert pyg.data.Batch is Batch\n"
+        "print('ok')\n")
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(root, "compat"), os.path.join(root, "compat", "pyg_free")])
+    out = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), env=env, capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr

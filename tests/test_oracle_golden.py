@@ -83,6 +83,36 @@ def test_one_step_and_momentum_match_reference(golden):
     assert abs(m - float(g["momentum"])) <= 1e-6 * abs(float(g["momentum"]))
 
 
+def test_driver_functions_match_reference(harness):
+    """The reference's own validate_one_step / momentum_conservation_loss / rollout outputs (harness.npz)."""
+    h = harness
+    meta, nh, steps, k = h["metadata"], int(h["nh"]), int(h["steps"]), int(h["k"])
+    c, e = torch.from_numpy(h["coords"]), torch.from_numpy(h["energy"])
+    W1 = int(h["one_step_window"])
+    sd = h["state_dict_one_step"]
+    for t, pe, te in zip(h["one_step_tested"], h["one_step_position_errors"], h["one_step_temperature_errors"]):
+        s0 = int(t) - W1
+        g = cpu_ref.preprocess(c[s0:s0 + W1].clone(), e[s0:s0 + W1].clone(), meta, None, None, 0.0, k, meta["dt"],
+                               meta["box_size"])
+        with torch.no_grad():
+            o = cpu_ref.encode_process_decode(sd, g["x"], g["edge_index"], g["edge_attr"], nh, steps)
+        st = cpu_ref.one_step(o["acceleration"], o["temp_rate"], c[s0:s0 + W1], e[s0:s0 + W1], c[s0 + W1], e[s0 + W1], meta)
+        assert abs(st["position_mse"] - float(pe)) <= 1e-6 * float(pe)
+        assert abs(st["temperature_mse"] - float(te)) <= 1e-6 * float(te)
+    assert float(h["one_step_position_error"]) == float(np.mean(h["one_step_position_errors"]))
+    # ragged three-graph batch: forward + momentum term
+    sizes = [int(v) for v in h["batch_sizes"]]
+    batch = torch.cat([torch.full((m,), i, dtype=torch.long) for i, m in enumerate(sizes)])
+    acc = torch.from_numpy(h["batch_acceleration"])
+    m = float(cpu_ref.momentum_conservation_loss(acc, batch, len(sizes), meta["dt"], float(h["momentum_weight"])))
+    assert abs(m - float(h["batch_momentum"])) <= 1e-6 * abs(float(h["batch_momentum"]))
+    # rollout: bit-identical trajectory
+    W2, R = int(h["rollout_window"]), int(h["rollout_steps"])
+    got = cpu_ref.rollout(h["state_dict_rollout"], nh, steps, c, e, meta, W2, 16, W2 + R)
+    assert torch.equal(got["Coordinates"], torch.from_numpy(h["rollout_coords"]))
+    assert torch.equal(got["InternalEnergy"], torch.from_numpy(h["rollout_energy"]))
+
+
 def test_knn_restatement_is_exact_vs_bruteforce():
     """The cKDTree-assisted k-NN must equal an exhaustive float32 search (ties by extended index)."""
     gen = torch.Generator().manual_seed(3)
