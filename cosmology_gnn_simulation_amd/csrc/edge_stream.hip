@@ -301,7 +301,13 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
                 const LdsW w0 = ring.wait_ready();
                 CGNN_STAMP(sk++);      // 1: released
                 f32x4 acc[HO];
-                p16_ready<HT>(pso, pdo);   // loaded a round ago, before the pieces wait_ready() has just waited for
+                // The P rows were requested a round ago.  With nh >= 2 that is before the pieces wait_ready() has just
+                // waited for (counted vmcnt retires in order).  With ONE hidden layer a round is two ring steps, the
+                // pieces of this layer were issued in the same step as the rows and BEFORE them, so the counted wait
+                // does not cover the rows: drain (found by test_all_rounds_in_one_launch_random_shapes[nh=1], a rare
+                // wrong tile when a row's load lost the race).
+                if (nh == 1) CGNN_VMCNT(0);
+                p16_ready<HT>(pso, pdo);
                 if (PMFMA) {
                     p16_accumulate<HT>(acc, pso, pdo, sel0, sel1);
                 } else {
