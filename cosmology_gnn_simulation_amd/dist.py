@@ -259,13 +259,15 @@ class ShardedForward:
         self.P = P
         # reference data flow (x_j): the node stream runs round by round with its halo exchanges and leaves every
         # round's Ps / Pd behind; the edge stream then is one launch (cgnn_edge_stream), as on one GPU
-        self.fused = m._can_fuse_rounds(P["rounds"], D)
+        self.image = P["image"]          # cgnn_edge_stream_run's chunk image (None: first-generation kernel or per round)
+        self.fused = self.image is not None or m._can_fuse_rounds(P["rounds"], D)
         self.x_all, self.ps, self.pd, self.agg, self.x_alt = self._buffers(D, H, sh.x_feat.device)
         ops.mlp_rows(P["enc_node"], sh.x_feat, out=self.x_all[:sh.n_owned])
         self._projected = False
         self._edges_pending = False
         # fused mode: the edge encoder runs inside cgnn_edge_stream when it has the rounds' shape
-        self._enc_in_stream = self.fused and m._encoder_fits_stream(P)
+        self._enc_in_stream = bool(self.image.enc_in) if self.image is not None else \
+            (self.fused and m._encoder_fits_stream(P))
         self.el = None if self._enc_in_stream else ops.mlp_rows(P["enc_edge"], sh.edge_attr, tiled=True)
         self.e_upd = self.el.empty_like() if m.message_source == "edge" else None
 
@@ -336,8 +338,12 @@ class ShardedForward:
         if self.fused and self._edges_pending:
             sh = self.sh
             enc = self.P["enc_edge"] if self._enc_in_stream else None
-            self.el = ops.edge_stream([p.edge for p in self.P["rounds"]], self.ps, self.pd, sh.src_local, sh.dst_local,
-                                      self.el, self.el, enc, sh.edge_attr if enc is not None else None)
+            if self.image is not None:
+                self.el = ops.edge_stream_run(self.image, self.ps, self.pd, sh.src_local, sh.dst_local, self.el, self.el,
+                                              sh.edge_attr if self._enc_in_stream else None)
+            else:
+                self.el = ops.edge_stream([p.edge for p in self.P["rounds"]], self.ps, self.pd, sh.src_local,
+                                          sh.dst_local, self.el, self.el, enc, sh.edge_attr if enc is not None else None)
             self._edges_pending = False
 
     def decode(self) -> dict:

@@ -210,7 +210,8 @@ class GraphIndependent(nn.Module):
 class _PackedProcessor:
     """Packed weights of one InteractionNetwork round."""
 
-    def __init__(self, net: "InteractionNetwork", latent: int, edge_precision, node_precision):
+    def __init__(self, net: "InteractionNetwork", latent: int, edge_precision, node_precision,
+                 keep_32_row_edges: bool = False):
         e_lin, e_ln = _split_mlp(net.edge_model)
         n_lin, n_ln = _split_mlp(net.node_model)
         if e_ln is None or n_ln is None:
@@ -226,7 +227,8 @@ class _PackedProcessor:
         self.ws = ops.PackedLinear(w1e, None, edge_precision, 0, D)
         self.wd = ops.PackedLinear(w1e, b1e, edge_precision, D, D)
         self.edge = _pack_mlp(net.edge_model, edge_precision, first_layer_cols=(2 * D, D))
-        if self.edge.precision == _lib.BF16 and D <= 128 and self.edge.hidden <= 128 and \
+        # keep_32_row_edges: the model runs its edge stream through cgnn_edge_stream_run, which takes the 32-row packing
+        if not keep_32_row_edges and self.edge.precision == _lib.BF16 and D <= 128 and self.edge.hidden <= 128 and \
                 self.edge.lds_bytes() <= _lib.LDS_WEIGHT_BUDGET:
             # weights fit in LDS: use the 16-edge-per-wave kernel (its own packing + P-table format)
             self.edge = _pack_mlp(net.edge_model, "bf16_n16", first_layer_cols=(2 * D, D))
@@ -288,7 +290,7 @@ def _run_round(p: _PackedProcessor, x: torch.Tensor, e: torch.Tensor, src, dst, 
 
 
 def _run_rounds_fused(rounds, x: torch.Tensor, e, src, dst, fixed_k: int, agg: Optional[torch.Tensor],
-                      encoder=None, edge_attr: Optional[torch.Tensor] = None):
+                      encoder=None, edge_attr: Optional[torch.Tensor] = None, image=None):
     """All residual rounds under the reference's data flow (aggregation of sender NODE latents): the node
     stream does not read the edge stream, so it runs first and leaves every round's Ps / Pd tables behind (the node
     kernel's epilogue writes round i+1's); then one launch applies all edge updates while each edge tile stays in
@@ -309,7 +311,10 @@ def _run_rounds_fused(rounds, x: torch.Tensor, e, src, dst, fixed_k: int, agg: O
         x = ops.node_block(p.node, p.wx, p.wa, x, agg, x, True, nxt)
     # `encoder` (the packed edge encoder) given: the initial edge latents are computed inside the same launch and
     # never written to memory (e is None then)
-    e = ops.edge_stream([p.edge for p in rounds], ps_all, pd_all, src, dst, e, e, encoder, edge_attr)
+    if image is not None:      # cgnn_edge_stream_run: the rounds (and the encoder, if it is part of the image) as one image
+        e = ops.edge_stream_run(image, ps_all, pd_all, src, dst, e, e, edge_attr if image.enc_in else None)
+    else:
+        e = ops.edge_stream([p.edge for p in rounds], ps_all, pd_all, src, dst, e, e, encoder, edge_attr)
     return x, e
 
 
@@ -391,7 +396,10 @@ class EncodeProcessDecode(nn.Module):
         self.node_precision = "fp32"
         self.edge_precision = "fp32"
         self.locality_sort = True     # run in the k-NN build's spatial order when the graph carries it
-        self.fuse_rounds = True       # x_j mode: all rounds of the edge stream in one launch (cgnn_edge_stream)
+        self.fuse_rounds = True       # x_j mode: all rounds of the edge stream in one launch
+        # which one-launch kernel: "tile32" = cgnn_edge_stream_run (32-edge MFMA tiles, one wave per SIMD, default),
+        # "tile16" = cgnn_edge_stream (16-edge tiles, two waves per SIMD; the first generation, kept for comparison)
+        self.edge_stream_kernel = "tile32"
         self._packed = None
         self._train_packed = None
 
@@ -411,20 +419,28 @@ class EncodeProcessDecode(nn.Module):
 
     def _pack(self, node_in: int, edge_in: int):
         self._materialize_all(node_in, edge_in)
-        key = _params_key(self, self.node_precision, self.edge_precision)
+        key = _params_key(self, self.node_precision, self.edge_precision, self.fuse_rounds, self.message_source,
+                          self.edge_stream_kernel)
         if self._packed is not None and self._packed[0] == key:
             return self._packed[1]
-        D = self._latent_size
+        D, H, nh, L = self._latent_size, self._mlp_hidden_size, self._mlp_num_hidden_layers, len(self.processor)
+        # cgnn_edge_stream_run (all rounds of the edge stream in one launch, 32-edge tiles) under the reference's data flow
+        tile32 = (self.fuse_rounds and self.message_source == "x_j" and self.edge_stream_kernel == "tile32" and L > 0 and
+                  ops._prec(self.edge_precision) == _lib.BF16 and ops.StreamImage.supported(D, H, nh, L))
         enc_edge = _pack_mlp(self.encoder.edge_model, self.edge_precision)
-        if enc_edge.precision == _lib.BF16 and enc_edge.in_dim <= 32 and D <= 128 and enc_edge.hidden <= 128 and \
-                enc_edge.lds_bytes() <= _lib.LDS_WEIGHT_BUDGET:
+        enc_in_image = tile32 and ops.StreamImage.supported(D, H, nh, L, enc_edge.in_dim)
+        if not tile32 and enc_edge.precision == _lib.BF16 and enc_edge.in_dim <= 32 and D <= 128 and \
+                enc_edge.hidden <= 128 and enc_edge.lds_bytes() <= _lib.LDS_WEIGHT_BUDGET:
             enc_edge = _pack_mlp(self.encoder.edge_model, "bf16_n16")    # 16-edge-per-wave encoder, TILED32 output
+        rounds = [_PackedProcessor(net, D, self.edge_precision, self.node_precision, keep_32_row_edges=tile32)
+                  for net in self.processor]
         packed = dict(
             enc_node=_pack_mlp(self.encoder.node_model, self.node_precision),
             enc_edge=enc_edge,
-            rounds=[_PackedProcessor(net, D, self.edge_precision, self.node_precision) for net in self.processor],
+            rounds=rounds,
             dec_acc=_pack_mlp(self.decoder_acc, self.node_precision),
             dec_tr=_pack_mlp(self.decoder_temp_rate, self.node_precision),
+            image=ops.StreamImage([p.edge for p in rounds], enc_edge if enc_in_image else None) if tile32 else None,
         )
         self._packed = (key, packed)
         return packed
@@ -534,8 +550,9 @@ class EncodeProcessDecode(nn.Module):
                 edge_attr = ops.gather_rows(edge_attr.view(n, -1), order).view(n * fixed_k, -1)
             P = self._pack(x.shape[1], edge_attr.shape[1])
             xl = ops.mlp_rows(P["enc_node"], x)
-            fuse = self._can_fuse_rounds(P["rounds"], xl.shape[1])
-            enc_in_stream = fuse and self._encoder_fits_stream(P)
+            image = P["image"]
+            fuse = image is not None or self._can_fuse_rounds(P["rounds"], xl.shape[1])
+            enc_in_stream = bool(image.enc_in) if image is not None else (fuse and self._encoder_fits_stream(P))
             # edge latents live in TILED32 layout; in the fused path the encoder runs inside cgnn_edge_stream
             el = None if enc_in_stream else ops.mlp_rows(P["enc_edge"], edge_attr, tiled=True)
             H = P["rounds"][0].ws.out_dim if P["rounds"] else 0
@@ -552,7 +569,7 @@ class EncodeProcessDecode(nn.Module):
             rounds = P["rounds"]
             if fuse:
                 xl, el = _run_rounds_fused(rounds, xl, el, src, dst, fixed_k, agg,
-                                           P["enc_edge"] if enc_in_stream else None, edge_attr)
+                                           P["enc_edge"] if enc_in_stream else None, edge_attr, image)
                 rounds = []
             for i, p in enumerate(rounds):
                 # residual streams updated in place (reference graph_network.py:181-182); the node kernel also

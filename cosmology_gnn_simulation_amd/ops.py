@@ -316,6 +316,73 @@ def edge_stream(mlps: Sequence[PackedMLP], ps_all: torch.Tensor, pd_all: torch.T
     return e_out
 
 
+class StreamImage:
+    """All rounds' edge models (and optionally the edge encoder in front) as the contiguous chunk image
+    ``cgnn_edge_stream_run`` cycles through its LDS ring (``cgnn_edge_stream_image_build``).  The models must be
+    packed ``"bf16"`` with ``hidden == latent`` in {32, 64, 128}; ``supported()`` says whether a shape qualifies."""
+
+    @staticmethod
+    def supported(latent: int, hidden: int, nh: int, rounds: int, enc_in: Optional[int] = None) -> bool:
+        if hidden != latent or rounds < 1 or (enc_in is not None and enc_in > 16):
+            return False
+        return _lib.load().cgnn_edge_stream_image_bytes(latent, nh, rounds, 1 if enc_in is not None else 0) > 0
+
+    def __init__(self, mlps: Sequence[PackedMLP], encoder: Optional[PackedMLP] = None):
+        lib = _lib.load()
+        self.rounds = len(mlps)
+        self.latent = mlps[0].out_dim
+        self.nh = mlps[0].num_hidden_layers
+        self.enc_in = encoder.in_dim if encoder is not None else 0
+        if any(m.precision != BF16 for m in mlps) or (encoder is not None and encoder.precision != BF16):
+            raise CgnnError("StreamImage: the edge models must be packed 'bf16'")
+        nbytes = lib.cgnn_edge_stream_image_bytes(self.latent, self.nh, self.rounds, 1 if encoder is not None else 0)
+        if nbytes == 0:
+            raise CgnnError(f"StreamImage: latent {self.latent} is not built (hidden == latent in {{32, 64, 128}})")
+        dev = mlps[0].layers[0].packed.device
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        arr = (Mlp * self.rounds)(*[m.struct() for m in mlps])
+        enc = encoder.struct() if encoder is not None else None
+        check(lib.cgnn_edge_stream_image_build(arr, self.rounds, C.byref(enc) if enc is not None else None, self.latent,
+                                               self.buf.data_ptr(), nbytes, stream_ptr(dev)), "cgnn_edge_stream_image_build")
+        self._keep = (list(mlps), encoder)     # the copies are asynchronous: keep the sources alive
+
+
+def edge_stream_run(image: StreamImage, ps_all: torch.Tensor, pd_all: torch.Tensor, src: torch.Tensor, dst: torch.Tensor,
+                    e_in: Optional[TiledRows], e_out: Optional[TiledRows] = None,
+                    edge_attr: Optional[torch.Tensor] = None) -> TiledRows:
+    """All residual edge updates of ``image`` in one launch (``cgnn_edge_stream_run``).  ``ps_all`` / ``pd_all``:
+    ``[rounds, N, latent]`` bf16 tables in ``CGNN_P_BF16_S32`` format.  When the image starts with the encoder the
+    initial latents come from ``edge_attr`` and ``e_in`` is ignored."""
+    src, dst = i32c(src, "src"), i32c(dst, "dst")
+    ne, latent = src.numel(), image.latent
+    if image.enc_in:
+        if edge_attr is None:
+            raise CgnnError("edge_stream_run: this image starts with the encoder and needs edge_attr")
+        edge_attr = f32c(edge_attr, "edge_attr")
+        if edge_attr.shape != (ne, image.enc_in):
+            raise CgnnError(f"edge_stream_run: edge_attr must be [E, {image.enc_in}]")
+        e_in = None
+    elif not isinstance(e_in, TiledRows) or e_in.n != ne or e_in.width != latent:
+        raise CgnnError("edge_stream_run: e_in must be the TiledRows edge latents")
+    if e_out is None:
+        e_out = TiledRows(ne, latent, src.device) if e_in is None else e_in.empty_like()
+    for t, name in ((ps_all, "ps_all"), (pd_all, "pd_all")):
+        require_device(t, name)
+        if t.dtype != torch.bfloat16 or not t.is_contiguous() or t.dim() != 3 or t.shape[0] != image.rounds or \
+                t.shape[2] != latent:
+            raise CgnnError(f"edge_stream_run: {name} must be a contiguous bfloat16 [rounds, N, latent] table")
+    if dst.numel() != ne or e_out.n != ne or e_out.width != latent:
+        raise CgnnError("edge_stream_run: src/dst/e_out do not match the edge latents")
+    with _timed("edge_stream", src.device):
+        check(_lib.load().cgnn_edge_stream_run(image.buf.data_ptr(), image.buf.numel(), latent, image.nh, image.rounds,
+                                               image.enc_in, ps_all.data_ptr(), pd_all.data_ptr(), ps_all.stride(0),
+                                               src.data_ptr(), dst.data_ptr(), ne,
+                                               e_in.buf.data_ptr() if e_in is not None else None, e_out.buf.data_ptr(),
+                                               ptr(edge_attr), edge_attr.stride(0) if edge_attr is not None else 0,
+                                               stream_ptr(src.device)), "cgnn_edge_stream_run")
+    return e_out
+
+
 def aggregate(table, gather: Optional[torch.Tensor], dst: Optional[torch.Tensor], num_nodes: int,
               fixed_k: int = 0, num_edges: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``out[i] = sum_{e: dst[e]==i} table[gather[e] if gather is not None else e]``.  ``table`` is a row-major

@@ -202,6 +202,28 @@ int cgnn_edge_stream(const cgnn_mlp* rounds, int32_t num_rounds, const void* ps_
                      const float* e_in, float* e_out, int32_t latent, const cgnn_mlp* encoder, const float* edge_attr,
                      int32_t ld_attr, void* stream);
 
+/* ---- the same, second generation: 32 edges per MFMA tile, one wave per SIMD, two tiles per wave ---------------------
+ * graph_network.py:57 (optional edge encoder) and :89-90,182 for round = 0..L-1, as cgnn_edge_stream, for
+ * hidden == latent in {32, 64, 128}.  The layers of all rounds travel as one contiguous IMAGE of self-contained chunks
+ * (packed CGNN_BF16 weights followed by the layer's bias and, for output layers, LayerNorm gamma / beta) that the kernel
+ * cycles through a four-slot LDS ring; build it once per model:
+ *   cgnn_edge_stream_image_bytes  size of the image (0 when the shape is not supported)
+ *   cgnn_edge_stream_image_build  rounds[r] = edge model of round r (CGNN_BF16, layer[0] = the We column block as for
+ *                                 cgnn_edge_block, LayerNorm required); encoder = NULL or the edge encoder (CGNN_BF16,
+ *                                 <= 16 input features, LayerNorm); device-to-device copies on `stream`
+ *   cgnn_edge_stream_run          ps_all / pd_all: CGNN_P_BF16_S32 tables of all rounds (round r at element
+ *                                 r * round_stride); e_in / e_out: CGNN_TILED32 (may alias); enc_in_dim > 0: the image
+ *                                 starts with the encoder, the initial latents are computed from edge_attr [E, ld_attr]
+ *                                 in the launch and e_in is ignored
+ * Arithmetic: bf16 operands, f32 accumulation, f32 LayerNorm and residual (as cgnn_edge_block with CGNN_BF16). */
+size_t cgnn_edge_stream_image_bytes(int32_t latent, int32_t num_hidden_layers, int32_t num_rounds, int32_t with_encoder);
+int cgnn_edge_stream_image_build(const cgnn_mlp* rounds, int32_t num_rounds, const cgnn_mlp* encoder, int32_t latent,
+                                 void* image, size_t image_bytes, void* stream);
+int cgnn_edge_stream_run(const void* image, size_t image_bytes, int32_t latent, int32_t num_hidden_layers,
+                         int32_t num_rounds, int32_t enc_in_dim, const void* ps_all, const void* pd_all,
+                         int64_t round_stride, const int32_t* src, const int32_t* dst, int64_t num_edges,
+                         const float* e_in, float* e_out, const float* edge_attr, int32_t ld_attr, void* stream);
+
 /* ---- backward of a row-wise MLP (+LayerNorm): the node stream of train.py:263 ------------------------
  * In reference-faithful mode only the node path carries gradient (the edge models' parameters get
  * none), so training needs the backward of cgnn_mlp_rows / cgnn_node_block and the transpose of the

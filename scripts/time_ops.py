@@ -19,6 +19,7 @@ ap.add_argument("--node-precision", default="fp32")
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--mp-steps", type=int, default=10, help="rounds for the edge_stream line")
 ap.add_argument("--only", default=None, help="time just this op")
+ap.add_argument("--stream-kernel", default="tile32", choices=["tile32", "tile16"])
 a = ap.parse_args()
 dev = "cuda"
 n, k, d = a.particles, a.neighbors, a.latent
@@ -29,6 +30,7 @@ m = graph_network.EncodeProcessDecode(d, d, 2, 1, 3)
 m.load_state_dict(synthetic.make_state_dict(d, d, 2, 1, 3))
 m = m.to(dev).eval()
 m.edge_precision, m.node_precision = a.edge_precision, a.node_precision
+m.fuse_rounds = False          # the single-round ops below use the per-round packing
 src, dst, fk = graph_network._graph_arrays(g, n)
 order, inv, src, dst = graph_network._locality_plan(g, n, fk, src)
 P = m._pack(17, 4)
@@ -65,18 +67,27 @@ L = a.mp_steps
 mL = graph_network.EncodeProcessDecode(d, d, 2, L, 3)
 mL.load_state_dict(synthetic.make_state_dict(d, d, 2, L, 3))
 mL = mL.to(dev).eval()
-mL.edge_precision, mL.node_precision = a.edge_precision, a.node_precision
-roundsL = mL._pack(17, 4)["rounds"]
+mL.edge_precision, mL.node_precision, mL.edge_stream_kernel = a.edge_precision, a.node_precision, a.stream_kernel
+PL_ = mL._pack(17, 4)
+roundsL = PL_["rounds"]
 if a.edge_precision == "bf16" and (not a.only or a.only.startswith("edge_stream")):
     ps_all = torch.randn(L, n, d, device=dev).to(torch.bfloat16)
     pd_all = torch.randn(L, n, d, device=dev).to(torch.bfloat16)
-    t("edge_stream", lambda: ops.edge_stream([r.edge for r in roundsL], ps_all, pd_all, src, dst, e, e),
-      2 * E * d * 4 + 2 * E * 4 + L * 2 * n * d * 2, L * 6.0 * E * d * d)
-    PL_ = mL._pack(17, 4)
-    if mL._encoder_fits_stream(PL_):
-        t("edge_stream+enc", lambda: ops.edge_stream([r.edge for r in roundsL], ps_all, pd_all, src, dst, None, e,
-                                                     PL_["enc_edge"], ea),
-          E * d * 4 + E * 16 + 2 * E * 4 + L * 2 * n * d * 2, L * 6.0 * E * d * d + 2.0 * E * (32 * d + 2 * d * d))
+    enc_flops = 2.0 * E * (32 * d + 2 * d * d)
+    if PL_["image"] is not None:        # cgnn_edge_stream_run (32-edge tiles)
+        img0 = ops.StreamImage([r.edge for r in roundsL], None)
+        t("edge_stream", lambda: ops.edge_stream_run(img0, ps_all, pd_all, src, dst, e, e),
+          2 * E * d * 4 + 2 * E * 4 + L * 2 * n * d * 2, L * 6.0 * E * d * d)
+        if PL_["image"].enc_in:
+            t("edge_stream+enc", lambda: ops.edge_stream_run(PL_["image"], ps_all, pd_all, src, dst, None, e, ea),
+              E * d * 4 + E * 16 + 2 * E * 4 + L * 2 * n * d * 2, L * 6.0 * E * d * d + enc_flops)
+    else:
+        t("edge_stream", lambda: ops.edge_stream([r.edge for r in roundsL], ps_all, pd_all, src, dst, e, e),
+          2 * E * d * 4 + 2 * E * 4 + L * 2 * n * d * 2, L * 6.0 * E * d * d)
+        if mL._encoder_fits_stream(PL_):
+            t("edge_stream+enc", lambda: ops.edge_stream([r.edge for r in roundsL], ps_all, pd_all, src, dst, None, e,
+                                                         PL_["enc_edge"], ea),
+              E * d * 4 + E * 16 + 2 * E * 4 + L * 2 * n * d * 2, L * 6.0 * E * d * d + enc_flops)
 t("edge_block", lambda: ops.edge_block(p.edge, ps, pd, src, dst, e, e, None, True),
   2 * E * d * 4 + 2 * E * 4 + 2 * n * d * 4, 6.0 * E * d * d)
 t("aggregate x_j", lambda: ops.aggregate(x, src, dst, n, fk, E, agg), E * d * 4 + E * 4 + n * d * 4)

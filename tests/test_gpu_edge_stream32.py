@@ -1,0 +1,168 @@
+"""GPU: cgnn_edge_stream_run (all edge rounds in one launch, 32-edge MFMA tiles) against a torch emulation of its
+arithmetic -- bf16 operands, f32 accumulation, f32 LayerNorm and residual (reference graph_network.py:57,:89-90,:182 with
+the first Linear split into Ps[src] + Pd[dst] + We e).  The emulation rounds to bf16 exactly where the kernel does, so
+the two agree to accumulation-order noise plus the odd bf16 rounding flip: far below what a wrong bias, LayerNorm
+vector, fragment or tile would cost."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cosmology_gnn_simulation_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def bf(t):
+    return t.bfloat16().float()
+
+
+def _dot(a, w):      # bf16 operands, wide accumulation
+    return (bf(a).double() @ bf(w).double().t()).float()
+
+
+def _s32_table(p):
+    """logical [R, N, H] values -> bf16 table in CGNN_P_BF16_S32 order (include/cgnn.h): feature f = 32t+8g+4h+c sits
+    at h*(H/2) + (4t+g)*4 + c."""
+    H = p.shape[-1]
+    f = torch.arange(H, device=p.device)
+    t, g, h, c = f // 32, (f % 32) // 8, (f % 8) // 4, f % 4
+    pos = h * (H // 2) + (4 * t + g) * 4 + c
+    out = torch.empty_like(p)
+    out[..., pos] = p
+    return out.bfloat16().contiguous()
+
+
+def _rand_mlp(gen, fin, d, nh):
+    dims = [fin] + [d] * nh + [d]
+    lin = []
+    for i in range(nh + 1):
+        bound = 1.0 / np.sqrt(dims[i])
+        w = (torch.rand(dims[i + 1], dims[i], generator=gen) * 2 - 1) * bound
+        b = (torch.rand(dims[i + 1], generator=gen) * 2 - 1) * bound
+        lin.append((w.to(DEV), b.to(DEV)))
+    ln = ((1 + 0.1 * torch.randn(d, generator=gen)).to(DEV), (0.1 * torch.randn(d, generator=gen)).to(DEV))
+    return lin, ln
+
+
+def _emulate_mlp(lin, ln, first):
+    """first = pre-activation of layer 0 (bias included)."""
+    h = bf(torch.relu(first))
+    for w, b in lin[1:-1]:
+        h = bf(torch.relu(_dot(h, w) + b))
+    w, b = lin[-1]
+    out = _dot(h, w) + b
+    return F.layer_norm(out, (out.shape[1],), ln[0], ln[1], 1e-5)
+
+
+def _problem(seed, n, k, d, nh, rounds, with_encoder, ragged=0):
+    gen = torch.Generator().manual_seed(seed)
+    ne = n * k - ragged
+    src = torch.randint(0, n, (ne,), generator=gen, dtype=torch.int32).to(DEV)
+    dst = torch.randint(0, n, (ne,), generator=gen, dtype=torch.int32).to(DEV)
+    ps = bf(torch.randn(rounds, n, d, generator=gen)).to(DEV)
+    pd = bf(torch.randn(rounds, n, d, generator=gen)).to(DEV)
+    mlps = [_rand_mlp(gen, d, d, nh) for _ in range(rounds)]
+    enc = _rand_mlp(gen, 4, d, nh) if with_encoder else None
+    attr = (torch.randn(ne, 4, generator=gen) * 0.3).to(DEV)
+    e0 = torch.randn(ne, d, generator=gen).to(DEV)
+    return src, dst, ps, pd, mlps, enc, attr, e0
+
+
+def _emulate(src, dst, ps, pd, mlps, enc, attr, e0):
+    s, t = src.long(), dst.long()
+    if enc is not None:
+        lin, ln = enc
+        e = _emulate_mlp(lin, ln, _dot(attr, lin[0][0]) + lin[0][1])
+    else:
+        e = e0.clone()
+    for r, (lin, ln) in enumerate(mlps):
+        first = (ps[r][s] + pd[r][t]) + _dot(e, lin[0][0])           # the round's layer-0 bias lives in Pd
+        e = e + _emulate_mlp(lin, ln, first)
+    return e
+
+
+def _run(src, dst, ps, pd, mlps, enc, attr, e0):
+    packed = [ops.PackedMLP([(lin[0][0], None)] + lin[1:], ln, "bf16") for lin, ln in mlps]
+    penc = ops.PackedMLP(enc[0], enc[1], "bf16") if enc is not None else None
+    image = ops.StreamImage(packed, penc)
+    e_in = None if enc is not None else ops.TiledRows.from_rows(e0)
+    out = ops.edge_stream_run(image, _s32_table(ps), _s32_table(pd), src, dst, e_in, None, attr if enc is not None else None)
+    torch.cuda.synchronize()
+    return out.to_rows()
+
+
+CASES = [
+    # n, k, latent, nh, rounds, encoder, ragged (edges dropped from n*k: partial last tile)
+    (7, 5, 128, 2, 3, False, 0),            # 35 edges: one pair, second tile missing
+    (8, 8, 128, 2, 2, True, 0),             # exactly one pair
+    (100, 16, 128, 2, 10, True, 0),
+    (100, 16, 128, 2, 10, False, 3),
+    (1000, 16, 128, 1, 4, True, 0),         # one hidden layer
+    (600, 8, 128, 3, 2, False, 5),          # three hidden layers
+    (3000, 16, 64, 2, 5, True, 1),
+    (700, 8, 64, 1, 12, False, 0),
+    (900, 16, 32, 2, 3, True, 7),
+    (333, 8, 32, 3, 6, False, 0),
+    (14000, 16, 128, 2, 2, True, 0),        # 224,000 edges: several pairs per wave, uneven iteration counts
+    (9000, 16, 128, 2, 3, False, 11),
+    (20000, 8, 64, 2, 2, True, 9),
+]
+
+
+@pytest.mark.parametrize("n,k,d,nh,rounds,with_enc,ragged", CASES)
+def test_edge_stream_run_matches_bf16_emulation(n, k, d, nh, rounds, with_enc, ragged):
+    prob = _problem(1000 + n + d + rounds, n, k, d, nh, rounds, with_enc, ragged)
+    got = _run(*prob)
+    want = _emulate(*prob)
+    assert got.shape == want.shape
+    scale = float(want.abs().max())
+    err = (got - want).abs()
+    assert float(err.max()) <= 1e-2 * scale, (float(err.max()), scale, int(err.argmax()) // d)
+    assert float((got - want).norm() / want.norm()) <= 1e-3
+    # every tile was written: no row left at its initial value / garbage
+    assert torch.isfinite(got).all()
+
+
+def test_edge_stream_run_is_deterministic_and_in_place():
+    prob = _problem(5, 5000, 16, 128, 2, 4, False)
+    a = _run(*prob)
+    b = _run(*prob)
+    assert torch.equal(a, b)
+    src, dst, ps, pd, mlps, enc, attr, e0 = prob
+    packed = [ops.PackedMLP([(lin[0][0], None)] + lin[1:], ln, "bf16") for lin, ln in mlps]
+    image = ops.StreamImage(packed, None)
+    e = ops.TiledRows.from_rows(e0)
+    ops.edge_stream_run(image, _s32_table(ps), _s32_table(pd), src, dst, e, e)        # e_out aliases e_in
+    assert torch.equal(e.to_rows(), a)
+
+
+def test_edge_stream_run_one_round_at_a_time_equals_all_rounds():
+    """L launches of one round each (the latents cross memory between them) == one launch of L rounds: same code path,
+    so the same bits."""
+    prob = _problem(6, 3000, 16, 128, 2, 5, False, 2)
+    src, dst, ps, pd, mlps, enc, attr, e0 = prob
+    all_at_once = _run(*prob)
+    tps, tpd = _s32_table(ps), _s32_table(pd)
+    e = ops.TiledRows.from_rows(e0)
+    for r, (lin, ln) in enumerate(mlps):
+        image = ops.StreamImage([ops.PackedMLP([(lin[0][0], None)] + lin[1:], ln, "bf16")], None)
+        ops.edge_stream_run(image, tps[r:r + 1].contiguous(), tpd[r:r + 1].contiguous(), src, dst, e, e)
+    assert torch.equal(e.to_rows(), all_at_once)
+
+
+def test_edge_stream_image_rejects_what_it_cannot_hold():
+    gen = torch.Generator().manual_seed(0)
+    lin, ln = _rand_mlp(gen, 64, 64, 2)
+    good = ops.PackedMLP([(lin[0][0], None)] + lin[1:], ln, "bf16")
+    ops.StreamImage([good], None)
+    with pytest.raises(ops.CgnnError, match="bf16"):
+        ops.StreamImage([ops.PackedMLP([(lin[0][0], None)] + lin[1:], ln, "bf16_n16")], None)
+    assert not ops.StreamImage.supported(256, 256, 2, 3)
+    assert not ops.StreamImage.supported(128, 64, 2, 3)
+    assert not ops.StreamImage.supported(128, 128, 2, 3, enc_in=17)
+    assert ops.StreamImage.supported(128, 128, 2, 10, enc_in=4)
+    lin2, ln2 = _rand_mlp(gen, 64, 64, 1)
+    with pytest.raises(ops.CgnnError):       # rounds of different depth
+        ops.StreamImage([good, ops.PackedMLP([(lin2[0][0], None)] + lin2[1:], ln2, "bf16")], None)

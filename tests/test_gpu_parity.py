@@ -487,11 +487,24 @@ def test_locality_sorted_execution_is_bitwise_equivalent():
         assert torch.equal(a[key], b[key]), key
 
 
+def _same_edge_stream(a, b, kernel, ctx=None):
+    """Node outputs never depend on the edge stream: bit-identical.  Edge latents: the 16-edge one-launch
+    kernel repeats the per-round kernel's arithmetic exactly (identical bits); the 32-edge one uses another MFMA shape
+    and summation order, so the two bf16 computations agree to bf16 rounding noise."""
+    for key in ("acceleration", "temp_rate", "x_latent"):
+        assert torch.equal(a[key], b[key]), (key, ctx)
+    if kernel == "tile16":
+        assert torch.equal(a["edge_latent"], b["edge_latent"]), ctx
+    else:
+        assert rel_l2(a["edge_latent"], b["edge_latent"]) <= 1e-2, ctx
+
+
+@pytest.mark.parametrize("kernel", ["tile32", "tile16"])
 @pytest.mark.parametrize("n,k,latent,nh,steps", [(5000, 16, 128, 2, 3), (300, 8, 128, 2, 10), (3000, 16, 64, 1, 2),
                                                  (2600, 16, 32, 3, 1), (40000, 16, 128, 2, 2), (777, 8, 64, 2, 5)])
-def test_all_rounds_in_one_launch_is_bitwise_equivalent(n, k, latent, nh, steps):
-    """cgnn_edge_stream (reference data flow: the node stream first, then every edge update with the edge tile in
-    registers) against one launch per round: same arithmetic, so identical bits; and both against the oracle."""
+def test_all_rounds_in_one_launch_is_bitwise_equivalent(n, k, latent, nh, steps, kernel):
+    """All rounds of the edge stream in one launch (reference data flow: the node stream first, then every edge update
+    with the edge tile in registers) against one launch per round, and both against the oracle."""
     snap = synthetic.make_snapshot(n, seed=n)
     meta = synthetic.make_metadata()
     d = data_utils.preprocess(snap["Coordinates"][:W], snap["InternalEnergy"][:W], meta, None, None, 0.0, k, 0.01, 1.0)
@@ -499,7 +512,7 @@ def test_all_rounds_in_one_launch_is_bitwise_equivalent(n, k, latent, nh, steps)
     m = graph_network.EncodeProcessDecode(latent, latent, nh, steps, 3)
     m.load_state_dict(sd)
     m = m.to(DEV).eval()
-    m.edge_precision, m.node_precision = "bf16", "fp32x3"
+    m.edge_precision, m.node_precision, m.edge_stream_kernel = "bf16", "fp32x3", kernel
     with ops.OpTimer() as tm, torch.no_grad():
         a = m.forward_with_latents(d)
     assert "edge_stream" in tm.summary() and "edge_block" not in tm.summary()     # the fused path really ran
@@ -507,8 +520,7 @@ def test_all_rounds_in_one_launch_is_bitwise_equivalent(n, k, latent, nh, steps)
     with ops.OpTimer() as tm, torch.no_grad():
         b = m.forward_with_latents(d)
     assert "edge_block" in tm.summary() and "edge_stream" not in tm.summary()
-    for key in ("acceleration", "temp_rate", "x_latent", "edge_latent"):
-        assert torch.equal(a[key], b[key]), key
+    _same_edge_stream(a, b, kernel)
     want = cpu_ref.encode_process_decode(sd, d.x.cpu(), d.edge_index.cpu(), d.edge_attr.cpu(), nh, steps,
                                          return_latents=True)
     assert rel_err(a["acceleration"].cpu(), want["acceleration"]) <= TOL
@@ -519,10 +531,11 @@ def test_all_rounds_in_one_launch_is_bitwise_equivalent(n, k, latent, nh, steps)
     assert "edge_stream" not in tm.summary()
 
 
+@pytest.mark.parametrize("kernel", ["tile32", "tile16"])
 @pytest.mark.parametrize("seed", range(12))
-def test_all_rounds_in_one_launch_random_shapes(seed):
-    """Randomised shapes for cgnn_edge_stream (tile counts below, at and above the grid's wave count, odd numbers of
-    16-edge tiles, 1..12 rounds, 1..3 hidden layers): bit-identical to one launch per round."""
+def test_all_rounds_in_one_launch_random_shapes(seed, kernel):
+    """Randomised shapes for the one-launch edge stream (tile counts below, at and above the grid's wave count, odd
+    numbers of tiles, 1..12 rounds, 1..3 hidden layers) against one launch per round."""
     rng = np.random.default_rng(1000 + seed)
     latent = int(rng.choice([32, 64, 128]))
     k = int(rng.choice([8, 16]))
@@ -535,15 +548,14 @@ def test_all_rounds_in_one_launch_random_shapes(seed):
     m = graph_network.EncodeProcessDecode(latent, latent, nh, steps, 3)
     m.load_state_dict(synthetic.make_state_dict(latent, latent, nh, steps, 3, seed=seed + 3))
     m = m.to(DEV).eval()
-    m.edge_precision, m.node_precision = "bf16", "fp32x3"
+    m.edge_precision, m.node_precision, m.edge_stream_kernel = "bf16", "fp32x3", kernel
     with ops.OpTimer() as tm, torch.no_grad():
         a = m.forward_with_latents(d)
     assert "edge_stream" in tm.summary(), (latent, k, n, nh, steps)
     m.fuse_rounds = False
     with torch.no_grad():
         b = m.forward_with_latents(d)
-    for key in ("acceleration", "temp_rate", "x_latent", "edge_latent"):
-        assert torch.equal(a[key], b[key]), (key, latent, k, n, nh, steps)
+    _same_edge_stream(a, b, kernel, (latent, k, n, nh, steps))
 
 
 def test_edge_stream_rejects_what_it_cannot_run():
@@ -551,7 +563,7 @@ def test_edge_stream_rejects_what_it_cannot_run():
     m = graph_network.EncodeProcessDecode(d, d, 2, 2, 3)
     m.load_state_dict(synthetic.make_state_dict(d, d, 2, 2, 3))
     m = m.to(DEV).eval()
-    m.edge_precision, m.node_precision = "bf16", "fp32x3"
+    m.edge_precision, m.node_precision, m.edge_stream_kernel = "bf16", "fp32x3", "tile16"
     rounds = m._pack(17, 4)["rounds"]
     e = ops.TiledRows.from_rows(torch.zeros(n * k, d, device=DEV))
     src = torch.zeros(n * k, dtype=torch.int32, device=DEV)
