@@ -63,40 +63,14 @@ struct S32Args {
     int32_t enc_in_dim;      // > 0: the first nh + 1 chunks are the edge encoder, fed from edge_attr
 };
 
-// ---- vector-memory bookkeeping -------------------------------------------------------------------------------------
+// ---- vector-memory waits -------------------------------------------------------------------------------------------
 // A wave's vector-memory operations retire in issue order, so "X has landed" is a counted s_waitcnt: at most as many
-// operations outstanding as the wave has issued since X.  The counters below hold that number for the things the loop
-// waits on (wave-uniform scalars).  Counting too FEW later operations only waits longer; counting too many would be
-// wrong, so operations whose number is not certain (compiler-issued loads and stores) are simply not counted.
-struct VmTrack {
-    int a1, a2;    // since the LDS-DMA pieces of the chunk one / two steps ahead
-    int pa;        // since the last P-row load
-    __device__ __forceinline__ void op(int n = 1) {
-        a1 += n;
-        a2 += n;
-        pa += n;
-    }
-    __device__ __forceinline__ void piece() {
-        a1 += 1;
-        a2 = 0;
-        pa += 1;
-    }
-};
+// operations outstanding as the wave has issued since X.  The loop's operations come in a fixed order (see the
+// schedule at the kernel), so the counts are constants; a smaller count than the true one only waits longer.
 #define CGNN_S32_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-__device__ __forceinline__ void vm_wait_at_most(int n) {
-    n = __builtin_amdgcn_readfirstlane(n);
-    if (n >= 48) CGNN_S32_VMCNT(48);
-    else if (n >= 32) CGNN_S32_VMCNT(32);
-    else if (n >= 24) CGNN_S32_VMCNT(24);
-    else if (n >= 16) CGNN_S32_VMCNT(16);
-    else if (n >= 12) CGNN_S32_VMCNT(12);
-    else if (n >= 8) CGNN_S32_VMCNT(8);
-    else if (n >= 6) CGNN_S32_VMCNT(6);
-    else if (n >= 4) CGNN_S32_VMCNT(4);
-    else if (n >= 3) CGNN_S32_VMCNT(3);
-    else if (n >= 2) CGNN_S32_VMCNT(2);
-    else if (n >= 1) CGNN_S32_VMCNT(1);
-    else CGNN_S32_VMCNT(0);
+template <int N>
+__device__ __forceinline__ void vm_wait_const() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 typedef __attribute__((address_space(3))) void* LdsVoidPtrG;
@@ -105,39 +79,41 @@ typedef const __attribute__((address_space(1))) void* GlobalVoidPtrG;
 // ---- the ring -------------------------------------------------------------------------------------------------------
 // Four slots.  Step s computes out of slot s % 4.  Between the two tiles' blocks of step s every wave waits for its
 // own pieces of chunk s + 1 and meets the others at a barrier: chunk s + 1 is then complete for everybody, and
-// everybody has left step s - 1, whose slot is refilled with chunk s + 3 (pieces handed out between the MFMA groups
-// that follow).  A chunk is requested two and a half steps before its first use.
+// everybody has left step s - 1, whose slot is refilled with chunk s + 3 (pieces handed out between the MFMAs that
+// follow).  A chunk is requested two and a half steps before its first use.
 template <class G>
 struct Ring32 {
     const char* image;
-    VmTrack& vm;
     int count;           // chunks per tile pair
     int wave, lane;
     int slot;            // of the current step
-    int dma_chunk, dma_slot, dma_left;
-    __device__ __forceinline__ Ring32(const char* img, VmTrack& v, int cnt, int w, int l, int total_steps)
-        : image(img), vm(v), count(cnt), wave(w), lane(l), slot(0), dma_chunk(0), dma_slot(0), dma_left(total_steps) {}
-    __device__ __forceinline__ unsigned base() const {
-        return (unsigned)(uintptr_t)(LdsWeightPtr)(cgnn_smem) + (unsigned)slot * G::STRIDE;
+    int dma_chunk, dma_slot;
+    bool primed = false;
+    __device__ __forceinline__ Ring32(const char* img, int cnt, int w, int l)
+        : image(img), count(cnt), wave(w), lane(l), slot(0), dma_chunk(0), dma_slot(0) {}
+    __device__ __forceinline__ unsigned lds0() const { return (unsigned)(uintptr_t)(LdsWeightPtr)(cgnn_smem); }
+    __device__ __forceinline__ unsigned base() const { return lds0() + (unsigned)slot * G::STRIDE; }
+    // LDS byte address of the vector block (bias, gamma, beta) of the chunk `ahead` steps ahead of the current one
+    __device__ __forceinline__ unsigned vec_addr(int ahead) const {
+        return lds0() + (unsigned)((slot + ahead) & (CGNN_S32_SLOTS - 1)) * G::STRIDE + G::VEC_OFF;
     }
-    __device__ __forceinline__ LdsVecPtr vec() const { return (LdsVecPtr)(cgnn_smem + (unsigned)slot * G::STRIDE + G::VEC_OFF); }
+    // The refill never stops: past the last step it copies chunks nobody will read into slots nobody reads any more
+    // (always the slot of the step just left), which keeps every wait count a constant and the loop free of branches;
+    // the kernel drains them before it ends.
     __device__ __forceinline__ void piece(int i) {
-        if (dma_left > 0) {
-            const unsigned off = (unsigned)(wave + CGNN_S32_WAVES * i) * 1024u;
-            const char* src = image + (size_t)dma_chunk * G::STRIDE + off + lane * 16;
-            char* dst = cgnn_smem + (unsigned)dma_slot * G::STRIDE + off;
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_global_load_lds((GlobalVoidPtrG)src, (LdsVoidPtrG)dst, 16, 0, 0);
-            asm volatile("" ::: "memory");
-            vm.piece();
-        }
+#ifdef CGNN_S32_ABLATE_DMA     // developer timing build (wrong results): the ring is never refilled
+        if (primed) return;
+#endif
+        const unsigned off = (unsigned)(wave + CGNN_S32_WAVES * i) * 1024u;
+        const char* src = image + (size_t)dma_chunk * G::STRIDE + off + lane * 16;
+        char* dst = cgnn_smem + (unsigned)dma_slot * G::STRIDE + off;
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_global_load_lds((GlobalVoidPtrG)src, (LdsVoidPtrG)dst, 16, 0, 0);
+        asm volatile("" ::: "memory");
     }
     __device__ __forceinline__ void dma_done() {
-        if (dma_left > 0) {
-            --dma_left;
-            dma_chunk = dma_chunk + 1 == count ? 0 : dma_chunk + 1;
-            dma_slot = (dma_slot + 1) & (CGNN_S32_SLOTS - 1);
-        }
+        dma_chunk = dma_chunk + 1 == count ? 0 : dma_chunk + 1;
+        dma_slot = (dma_slot + 1) & (CGNN_S32_SLOTS - 1);
     }
     __device__ __forceinline__ void prime() {
         for (int c = 0; c < CGNN_S32_SLOTS - 1; ++c) {
@@ -147,14 +123,21 @@ struct Ring32 {
         CGNN_S32_VMCNT(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        vm.a1 = vm.a2 = 0;
+        primed = true;
     }
+    // `wait for everything but the newest N operations`, N = the pieces of the chunk two steps ahead, which were issued
+    // after the ones we need (N more if the caller has issued EXTRA operations of its own since)
+    template <int EXTRA>
+    __device__ __forceinline__ void wait_next_chunk() const {
+        vm_wait_const<G::NP + EXTRA>();
+    }
+    template <int EXTRA>
     __device__ __forceinline__ void sync_next() {
-        vm_wait_at_most(vm.a1);
+        wait_next_chunk<EXTRA>();
+#ifndef CGNN_S32_ABLATE_BARRIER
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
-        vm.a1 = vm.a2;
-        vm.a2 = 0;
     }
     __device__ __forceinline__ void advance() { slot = (slot + 1) & (CGNN_S32_SLOTS - 1); }
 };
@@ -162,7 +145,11 @@ struct Ring32 {
 // ---- per-tile registers ---------------------------------------------------------------------------------------------
 // 32 edges in the act layout of cgnn_common.hpp: edge on the MFMA column (lane & 31), for 32-feature tile t register i
 // of lane (r, h) holds feature 32 t + 8 (i >> 2) + 4 h + (i & 3).
-// a value parked in an accumulation register: only acc_put / acc_get touch it
+// Values parked in accumulation registers: only these helpers touch them.  Four at a time, because hipcc pads every
+// inline-asm statement whose outputs a vector instruction reads next with a wait state (one s_nop per statement).
+// (Leaving the moves to the compiler -- an empty asm with a "+a" operand -- does not work under pressure: the register
+// allocator then keeps the values architectural and spills them.  And do not hand a vector ELEMENT straight to
+// __builtin_bit_cast: clang reads element 0.)
 __device__ __forceinline__ unsigned acc_put(float v) {
     unsigned a;
     asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
@@ -173,13 +160,24 @@ __device__ __forceinline__ float acc_get(unsigned a) {
     asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
     return v;
 }
+__device__ __forceinline__ void acc_put4(unsigned& a0, unsigned& a1, unsigned& a2, unsigned& a3, float v0, float v1, float v2,
+                                         float v3) {
+    asm("v_accvgpr_write_b32 %0, %4\n\tv_accvgpr_write_b32 %1, %5\n\tv_accvgpr_write_b32 %2, %6\n\tv_accvgpr_write_b32 %3, %7"
+        : "=a"(a0), "=a"(a1), "=a"(a2), "=a"(a3)
+        : "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+}
+__device__ __forceinline__ void acc_get4(float& v0, float& v1, float& v2, float& v3, unsigned a0, unsigned a1, unsigned a2,
+                                         unsigned a3) {
+    asm("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7"
+        : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3)
+        : "a"(a0), "a"(a1), "a"(a2), "a"(a3));
+}
 template <int DT>
 struct Tile32 {
     unsigned evp[DT][16]; // f32 latent (the residual stream), parked in accumulation registers
     f32x16 acc[DT];       // accumulators of the layer in flight, then its output
     bf16x8 in[2 * DT];    // the layer's input operand: k-step 2 t + s = features 32 t + 16 s .. + 15 (fragment k order)
     float part[DT];       // LayerNorm partial sums
-    float keep[4];        // new latent values of an even affine slice, packed with the odd one that follows
     float mean, rstd;
 };
 
@@ -202,16 +200,19 @@ __device__ __forceinline__ void lds_wait2i(u32x4& a, u32x4& b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+a"(a), "+a"(b) : "n"(IMM));
 }
 
+// A block's MFMAs are numbered 0 .. M-1 ("slots"); `fill(slot)` runs right behind MFMA `slot` and a scheduling barrier
+// pins it there: the place for the OTHER tile's vector work and this wave's memory instructions, whose issue then
+// overlaps the matrix pipe (left alone, hipcc gathers the independent vector work in front of the block).
 struct NoFill32 {
-    template <int G>
+    template <int Q>
     __device__ __forceinline__ void run() const {}
 };
 template <class F>
 struct FnFill32 {
     F f;
-    template <int G>
+    template <int Q>
     __device__ __forceinline__ void run() const {
-        f(std::integral_constant<int, G>{});
+        f(std::integral_constant<int, Q>{});
     }
 };
 template <class F>
@@ -219,15 +220,46 @@ __device__ __forceinline__ FnFill32<F> make_fill(F f) {
     return FnFill32<F>{f};
 }
 
+template <int NROW, int KS>
+struct WBlock {
+    static constexpr int M = NROW * KS, GS = M < 4 ? M : 4, NG = M / GS, PD = CGNN_S32_PD;
+    // weight-fragment reads issued between MFMA `q` and its fill (fragment q + PD * GS, if the layer has one)
+    static constexpr int fragtop(int q) { return (q + PD * GS < M) ? 1 : 0; }
+    // ... in front of MFMAs (q0, q1]
+    static constexpr int frags_between(int q0, int q1) {
+        int n = 0;
+        for (int x = q0 + 1; x <= q1; ++x) n += fragtop(x);
+        return n;
+    }
+};
+
 // acc[o] += W[32 o .. 32 o + 31, :] . in ; fragment m = o * KS + ks (1 KiB, lane-linear) at addr + m * 1024.  The LDS
 // reads and their counted waits are written by hand (hipcc waits lgkmcnt(0) before every group otherwise); PD groups
-// of four fragments are in flight ahead of the MFMAs; `fill.run<g>()` is called after each group's MFMAs have been
-// issued: the place for the OTHER tile's vector work and this wave's memory instructions, whose issue then overlaps
-// the matrix pipe.  Rows are finished one after the other (o outermost).
+// of four fragments are in flight ahead of the MFMAs.  Rows are finished one after the other (o outermost).
+#ifdef CGNN_S32_DUMMY_FILL
+template <int N>
+__device__ __forceinline__ void dummy_fill(float& a, float& b, float& c, float& d) {
+    if constexpr (N > 0) {
+        asm volatile("v_add_f32 %0, %0, %0" : "+v"(a));
+        dummy_fill<N - 1>(b, c, d, a);
+    }
+}
+#endif
 template <int NROW, int KS, class Fill>
 __device__ __forceinline__ void wblock32(f32x16 (&acc)[NROW], const bf16x8 (&in)[KS], unsigned addr, const Fill& fill) {
-    constexpr int M = NROW * KS, GS = M < 4 ? M : 4, NG = M / GS, PD = CGNN_S32_PD, NBUF = PD + 1;
+#ifdef CGNN_S32_DUMMY_FILL
+    float dummy0 = 1.f, dummy1 = 2.f, dummy2 = 3.f, dummy3 = 4.f;
+#endif
+    typedef WBlock<NROW, KS> WB;
+    constexpr int M = WB::M, GS = WB::GS, NG = WB::NG, PD = WB::PD, NBUF = PD + 1;
     static_assert(M % GS == 0 && (GS == 4 || GS == 2 || GS == 1), "groups of four (two, one) fragments");
+    // issue index t -> fragment: rows in pairs, the two rows of a pair alternating (consecutive MFMAs then write
+    // different accumulators), or plainly row after row
+#ifdef CGNN_S32_ROWPAIR
+#define CGNN_S32_FRAG(t) ((NROW % 2 == 0) ? ((((t) / (2 * KS)) * 2 + (t) % 2) * KS + ((t) / 2) % KS) : (t))
+#else
+#define CGNN_S32_FRAG(t) (t)
+#endif
     const unsigned a = addr + (unsigned)(threadIdx.x & 63) * 16u;
     u32x4 buf[NBUF][GS];
     static_for_each([&](auto pc) __attribute__((always_inline)) {
@@ -235,19 +267,15 @@ __device__ __forceinline__ void wblock32(f32x16 (&acc)[NROW], const bf16x8 (&in)
         if constexpr (p < NG) {
             static_for_each([&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
-                buf[p][j] = lds_read_b128_acc<(p * GS + j) * 1024>(a);
+                buf[p][j] = lds_read_b128_acc<CGNN_S32_FRAG(p * GS + j) * 1024>(a);
             }, std::make_integer_sequence<int, GS>{});
         }
     }, std::make_integer_sequence<int, PD>{});
     static_for_each([&](auto gc) __attribute__((always_inline)) {
         constexpr int g = decltype(gc)::value;
-        if constexpr (g + PD < NG) {
-            static_for_each([&](auto jc) __attribute__((always_inline)) {
-                constexpr int j = decltype(jc)::value;
-                buf[(g + PD) % NBUF][j] = lds_read_b128_acc<((g + PD) * GS + j) * 1024>(a);
-            }, std::make_integer_sequence<int, GS>{});
-        }
-        constexpr int newer = ((g + PD < NG ? g + PD : NG - 1) - g) * GS;     // fragment reads issued after group g's
+        // fragments of groups <= g + PD - 1 have been requested (one read behind every MFMA: a burst of four at the
+        // top of a group queues behind the other waves' bursts at the LDS)
+        constexpr int newer = ((g + PD - 1 < NG ? g + PD - 1 : NG - 1) - g) * GS;     // fragment reads issued after group g's
         if constexpr (GS == 4)
             lds_wait4i<newer>(buf[g % NBUF][0], buf[g % NBUF][1], buf[g % NBUF][2], buf[g % NBUF][3]);
         else if constexpr (GS == 2)
@@ -255,21 +283,24 @@ __device__ __forceinline__ void wblock32(f32x16 (&acc)[NROW], const bf16x8 (&in)
         else
             lds_wait1i<newer>(buf[g % NBUF][0]);
         static_for_each([&](auto jc) __attribute__((always_inline)) {
-            constexpr int j = decltype(jc)::value, m = g * GS + j, o = m / KS, ks = m % KS;
+            constexpr int j = decltype(jc)::value, m = g * GS + j, fm = CGNN_S32_FRAG(m), o = fm / KS, ks = fm % KS;
             acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, buf[g % NBUF][j]), in[ks], acc[o], 0, 0,
                                                              0);
+            if constexpr (g + PD < NG) buf[(g + PD) % NBUF][j] = lds_read_b128_acc<CGNN_S32_FRAG((g + PD) * GS + j) * 1024>(a);
+            fill.template run<m>();
+#ifdef CGNN_S32_DUMMY_FILL      // developer timing build: N independent vector instructions behind every MFMA
+            dummy_fill<CGNN_S32_DUMMY_FILL>(dummy0, dummy1, dummy2, dummy3);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
         }, std::make_integer_sequence<int, GS>{});
-        fill.template run<g>();
     }, std::make_integer_sequence<int, NG>{});
+#undef CGNN_S32_FRAG
 }
-template <int NROW, int KS>
-struct WBlockGroups {
-    static constexpr int M = NROW * KS, GS = M < 4 ? M : 4, NG = M / GS;
-};
 
 // P rows (CGNN_P_BF16_S32: lane (r, h) owns the 16-byte pieces 2 t + s of its half of the row = the B operand of k-step
 // (t, s)) enter the accumulators through the matrix pipe: A = a constant 0/1 selector that copies k = 8 h' + j of
 // k-step s to row 16 s + 8 (j >> 2) + 4 h' + (j & 3).  acc[t] = Ps[src] + Pd[dst] (exact products, f32 sums).
+// 4 DT MFMAs = slots 0 .. 4 DT - 1.
 __device__ __forceinline__ bf16x8 p32_selector(int lane, int s) {
     const int m = lane & 31, hh = lane >> 5;
     bf16x8 a;
@@ -280,24 +311,43 @@ __device__ __forceinline__ bf16x8 p32_selector(int lane, int s) {
 template <int DT, class Fill>
 __device__ __forceinline__ void selp32(f32x16 (&acc)[DT], const bf16x8 (&ps)[2 * DT], const bf16x8 (&pd)[2 * DT], bf16x8 sel0,
                                        bf16x8 sel1, const Fill& fill) {
+#ifdef CGNN_S32_ABLATE_SELP
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    return;
+#endif
     static_for_each([&](auto tc) __attribute__((always_inline)) {
         constexpr int t = decltype(tc)::value;
         f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel0, ps[2 * t], c, 0, 0, 0);
+        fill.template run<4 * t>();
+        __builtin_amdgcn_sched_barrier(0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel1, ps[2 * t + 1], c, 0, 0, 0);
+        fill.template run<4 * t + 1>();
+        __builtin_amdgcn_sched_barrier(0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel0, pd[2 * t], c, 0, 0, 0);
+        fill.template run<4 * t + 2>();
+        __builtin_amdgcn_sched_barrier(0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel1, pd[2 * t + 1], c, 0, 0, 0);
         acc[t] = c;
-        fill.template run<t>();
+        fill.template run<4 * t + 3>();
+        __builtin_amdgcn_sched_barrier(0);
     }, std::make_integer_sequence<int, DT>{});
 }
 
-// P-row loads from inline asm (the compiler would guard registers loaded across the ring's LDS-DMA with vmcnt(0)).
-// The caller counts them (VmTrack) and calls p32_ready() behind its own wait.
+// P-row loads from inline asm (the compiler would guard registers loaded across the ring's LDS-DMA with vmcnt(0)),
+// straight into accumulation registers; 32-bit lane offset + uniform 64-bit table base.  The caller waits (counted)
+// and then calls p32_ready().
 template <int IDX>
-__device__ __forceinline__ bf16x8 p32_load(const __bf16* rowh) {     // rowh = table + row * H + h * (H / 2)
+__device__ __forceinline__ bf16x8 p32_load(unsigned off, const __bf16* table) {     // off = (row * H + h * (H / 2)) * 2
     u32x4 r;
-    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(r) : "v"(rowh), "n"(IDX * 16));
+#ifndef CGNN_S32_ABLATE_P
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(r) : "v"(off), "s"(table), "n"(IDX * 16));
+#else
+    r = u32x4{0u, 0u, 0u, 0u};
+#endif
     return __builtin_bit_cast(bf16x8, r);
 }
 template <int DT>
@@ -324,12 +374,18 @@ __device__ __forceinline__ void pack32_slice(Tile32<DT>& X) {
     const bf16x8 b = __builtin_bit_cast(bf16x8, v);
     X.in[2 * t + s] = RELU ? relu_bf16(b) : b;
 }
-template <int DT>
-struct Pack32 {
-    static constexpr int NS = 2 * DT;
-};
 template <bool RELU, int DT, int S0, int S1>
 __device__ __forceinline__ void pack32_run(Tile32<DT>& X) {
+#ifdef CGNN_S32_ABLATE_PACK     // (timing build: keep the layer's MFMAs alive)
+    if constexpr (S0 == 0 && S1 > 0) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const float keep_alive = X.acc[t][0];
+            asm volatile("" ::"v"(keep_alive));
+        }
+    }
+    return;
+#endif
     static_for_each([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value + S0;
         if constexpr (u < S1) pack32_slice<RELU, DT, u>(X);
@@ -347,36 +403,46 @@ __device__ __forceinline__ float half_swap_sum(float s) {     // s[lane] + s[lan
 // and the bf16 pack of the new ev as the next layer-0 operand.  Slices:
 //   [0, DT)            partial sums per feature tile                 DT                 total, mean
 //   [DT + 1, 2 DT + 1) centre, partial sums of squares               2 DT + 1           variance, rstd
-//   [2 DT + 2, 6 DT + 2) affine (+ residual) for (t, g): reads and rewrites the parked latent; every second one also
-//                        packs the eight new values of (t, s = g >> 1) as the next layer-0 operand
+//   [2 DT + 2, 4 DT + 2) affine (+ residual) for eight values (t, s): reads and rewrites the parked latent and packs
+//                        the new values as k-step (t, s) of the next layer-0 operand
+// The arithmetic runs on register pairs (v_pk_add / v_pk_mul / v_pk_fma_f32) in short independent chains: with one
+// wave per SIMD every instruction costs an issue slot of four cycles and a dependent one waits for its producer.
 template <int DT>
 struct Ln32 {
-    static constexpr int NS = 6 * DT + 2;
-    static constexpr int AFF0 = 2 * DT + 2, AFF1 = 6 * DT + 2;      // the affine slices
+    static constexpr int NS = 4 * DT + 2;
+    static constexpr int AFF0 = 2 * DT + 2;      // first affine slice
+    static constexpr int NAFF = 2 * DT;
 };
-// gamma / beta of the affine slices come through two register pairs filled by hand-issued LDS reads, one slice ahead
-// (left to the compiler, all 8 DT reads of a LayerNorm are hoisted to its top: 128 registers at latent 128, spills).
+// gamma / beta of the affine slices come through two register sets filled by hand-issued LDS reads, one slice ahead
+// (left to the compiler, all reads of a LayerNorm are hoisted to its top: 128 registers at latent 128, spills).
 struct LnVec32 {
-    u32x4 g[2], b[2];
+    u32x4 g[2][2], b[2][2];      // [set][feature group 2 s, 2 s + 1]
 };
 template <int IMM>
-__device__ __forceinline__ void ln32_vec_read(u32x4& g, u32x4& b, unsigned ga, unsigned ba) {
-    asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4" : "=&v"(g), "=&v"(b) : "v"(ga), "v"(ba), "n"(IMM));
+__device__ __forceinline__ void ln32_vec_read(u32x4& g0, u32x4& g1, u32x4& b0, u32x4& b1, unsigned ga, unsigned ba) {
+    asm volatile("ds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %4 offset:%7\n\t"
+                 "ds_read_b128 %2, %5 offset:%6\n\tds_read_b128 %3, %5 offset:%7"
+                 : "=&v"(g0), "=&v"(g1), "=&v"(b0), "=&v"(b1)
+                 : "v"(ga), "v"(ba), "n"(IMM), "n"(IMM + 32));
 }
 template <int NEWER>
-__device__ __forceinline__ void ln32_vec_wait(u32x4& g, u32x4& b) {
-    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(g), "+v"(b) : "n"(NEWER));
+__device__ __forceinline__ void ln32_vec_wait(u32x4& g0, u32x4& g1, u32x4& b0, u32x4& b1) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(g0), "+v"(g1), "+v"(b0), "+v"(b1) : "n"(NEWER > 11 ? 11 : NEWER));
 }
-// NEWER: LDS operations this wave has issued since the PREVIOUS slice ran (the weight-fragment reads at the top of the
-// MFMA groups in between): the affine slice waits for its own vectors and leaves those in flight.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// NEWER: LDS operations this wave has issued since the PREVIOUS slice ran (the weight-fragment reads behind the MFMAs
+// in between): the affine slice waits for its own vectors and leaves those in flight.  A smaller number than the true
+// one only waits longer.
 template <bool RES, int DT, int U, int NEWER>
 __device__ __forceinline__ void ln32_slice(Tile32<DT>& X, LnVec32& V, unsigned ga, unsigned ba) {
     constexpr int D = 32 * DT;
     typedef Ln32<DT> LN;
     if constexpr (U < DT) {
         const f32x16& v = X.acc[U];
-        X.part[U] = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
-                    (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+        const f32x2 a0 = f32x2{v[0], v[1]} + f32x2{v[2], v[3]}, a1 = f32x2{v[4], v[5]} + f32x2{v[6], v[7]};
+        const f32x2 a2 = f32x2{v[8], v[9]} + f32x2{v[10], v[11]}, a3 = f32x2{v[12], v[13]} + f32x2{v[14], v[15]};
+        const f32x2 s = (a0 + a1) + (a2 + a3);
+        X.part[U] = s[0] + s[1];
     } else if constexpr (U == DT) {
         float s = X.part[0];
 #pragma unroll
@@ -385,92 +451,145 @@ __device__ __forceinline__ void ln32_slice(Tile32<DT>& X, LnVec32& V, unsigned g
     } else if constexpr (U < 2 * DT + 1) {
         constexpr int t = U - DT - 1;
         f32x16& v = X.acc[t];
-        float q = 0.f;
+        const f32x2 m2 = {X.mean, X.mean};
+        f32x2 q[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            v[i] -= X.mean;
-            q = fmaf(v[i], v[i], q);
+        for (int i = 0; i < 16; i += 2) {
+            const f32x2 d = f32x2{v[i], v[i + 1]} - m2;
+            v[i] = d[0];
+            v[i + 1] = d[1];
+            q[(i >> 1) & 3] = __builtin_elementwise_fma(d, d, q[(i >> 1) & 3]);
         }
-        X.part[t] = q;
+        const f32x2 qq = (q[0] + q[1]) + (q[2] + q[3]);
+        X.part[t] = qq[0] + qq[1];
     } else if constexpr (U == 2 * DT + 1) {
         float q = X.part[0];
 #pragma unroll
         for (int t = 1; t < DT; ++t) q += X.part[t];
-        X.rstd = 1.0f / sqrtf(half_swap_sum(q) * (1.0f / D) + 1e-5f);
-        ln32_vec_read<0>(V.g[0], V.b[0], ga, ba);                      // vectors of the first affine slice
-    } else if constexpr (U < LN::AFF1) {
-        constexpr int k = U - LN::AFF0, t = k >> 2, g = k & 3;
-        if constexpr (k + 1 < 4 * DT) {
-            constexpr int t1 = (k + 1) >> 2, g1 = (k + 1) & 3;
-            ln32_vec_read<(32 * t1 + 8 * g1) * 4>(V.g[(k + 1) & 1], V.b[(k + 1) & 1], ga, ba);
-            ln32_vec_wait<NEWER + 2>(V.g[k & 1], V.b[k & 1]);
+        X.rstd = __builtin_amdgcn_rsqf(half_swap_sum(q) * (1.0f / D) + 1e-5f);
+#ifndef CGNN_S32_ABLATE_LNVEC
+        ln32_vec_read<0>(V.g[0][0], V.g[0][1], V.b[0][0], V.b[0][1], ga, ba);      // vectors of the first affine slice
+#else
+        V.g[0][0] = V.g[0][1] = V.b[0][0] = V.b[0][1] = V.g[1][0] = V.g[1][1] = V.b[1][0] = V.b[1][1] = u32x4{0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};
+#endif
+    } else {
+        constexpr int k = U - LN::AFF0, t = k >> 1, sx = k & 1, cur = k & 1, nxt = cur ^ 1;
+#ifndef CGNN_S32_ABLATE_LNVEC
+        if constexpr (k + 1 < LN::NAFF) {
+            constexpr int t1 = (k + 1) >> 1, s1 = (k + 1) & 1;
+            ln32_vec_read<(32 * t1 + 16 * s1) * 4>(V.g[nxt][0], V.g[nxt][1], V.b[nxt][0], V.b[nxt][1], ga, ba);
+            ln32_vec_wait<NEWER + 4>(V.g[cur][0], V.g[cur][1], V.b[cur][0], V.b[cur][1]);
         } else {
-            ln32_vec_wait<NEWER>(V.g[k & 1], V.b[k & 1]);
+            ln32_vec_wait<NEWER>(V.g[cur][0], V.g[cur][1], V.b[cur][0], V.b[cur][1]);
         }
-        const f32x4 gm = __builtin_bit_cast(f32x4, V.g[k & 1]);
-        const f32x4 bt = __builtin_bit_cast(f32x4, V.b[k & 1]);
-        float e[4];
+#endif
+        const f32x2 r2 = {X.rstd, X.rstd};
+        f32x2 e[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float w = gm[c] * X.rstd;
-            if (RES)
-                e[c] = fmaf(X.acc[t][4 * g + c], w, acc_get(X.evp[t][4 * g + c]) + bt[c]);
-            else
-                e[c] = fmaf(X.acc[t][4 * g + c], w, bt[c]);
-            X.evp[t][4 * g + c] = acc_put(e[c]);
-        }
-        if constexpr ((g & 1) == 0) {
+        for (int gg = 0; gg < 2; ++gg) {
+            const f32x4 gm = __builtin_bit_cast(f32x4, V.g[cur][gg]);
+            const f32x4 bt = __builtin_bit_cast(f32x4, V.b[cur][gg]);
+            constexpr int i0 = 8 * sx;
+            const int i = i0 + 4 * gg;
+            f32x2 base[2] = {f32x2{bt[0], bt[1]}, f32x2{bt[2], bt[3]}};
+#ifndef CGNN_S32_ABLATE_LNACC
+            if (RES) {
+                float p0, p1, p2, p3;
+                acc_get4(p0, p1, p2, p3, X.evp[t][i], X.evp[t][i + 1], X.evp[t][i + 2], X.evp[t][i + 3]);
+                base[0] += f32x2{p0, p1};
+                base[1] += f32x2{p2, p3};
+            }
+#endif
 #pragma unroll
-            for (int c = 0; c < 4; ++c) X.keep[c] = e[c];
-        } else {
-            u32x4 v;
-            v[0] = pack_bf16(X.keep[0], X.keep[1]);
-            v[1] = pack_bf16(X.keep[2], X.keep[3]);
-            v[2] = pack_bf16(e[0], e[1]);
-            v[3] = pack_bf16(e[2], e[3]);
-            X.in[2 * t + (g >> 1)] = __builtin_bit_cast(bf16x8, v);
+            for (int c = 0; c < 2; ++c) {
+                const f32x2 w = f32x2{gm[2 * c], gm[2 * c + 1]} * r2;
+                const f32x2 d = {X.acc[t][i + 2 * c], X.acc[t][i + 2 * c + 1]};
+                e[2 * gg + c] = __builtin_elementwise_fma(d, w, base[c]);
+            }
+#ifndef CGNN_S32_ABLATE_LNACC
+            acc_put4(X.evp[t][i], X.evp[t][i + 1], X.evp[t][i + 2], X.evp[t][i + 3], e[2 * gg][0], e[2 * gg][1],
+                     e[2 * gg + 1][0], e[2 * gg + 1][1]);
+#endif
         }
+        u32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = pack_bf16(e[c][0], e[c][1]);
+        X.in[2 * t + sx] = __builtin_bit_cast(bf16x8, v);
     }
 }
 // slices [S0, S1); NEWER0 applies to the first of them (see ln32_slice), the others follow it directly
 template <bool RES, int DT, int S0, int S1, int NEWER0>
 __device__ __forceinline__ void ln32_run(Tile32<DT>& X, LnVec32& V, unsigned ga, unsigned ba) {
+#ifdef CGNN_S32_ABLATE_LN       // (timing build: keep the layer's MFMAs alive)
+    if constexpr (S0 == 0 && S1 > 0) {
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const float keep_alive = X.acc[t][0];
+            asm volatile("" ::"v"(keep_alive));
+        }
+    }
+    return;
+#endif
     static_for_each([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value + S0;
         if constexpr (u < S1) ln32_slice<RES, DT, u, (u == S0 ? NEWER0 : 0)>(X, V, ga, ba);
     }, std::make_integer_sequence<int, (S1 > S0 ? S1 - S0 : 0)>{});
 }
 
-template <int DT>
-__device__ __forceinline__ void bias_fill32(f32x16 (&acc)[DT], LdsVecPtr b, int h) {
+// acc = bias (rows [T0, T1) of the tile); plain LDS loads, placed by the caller where their latency is covered
+template <int DT, int T0, int T1>
+__device__ __forceinline__ void bias_rows32(f32x16 (&acc)[DT], unsigned vec_addr, int h) {
+    const LdsVecPtr b = (LdsVecPtr)(uintptr_t)vec_addr;
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+    for (int t = T0; t < T1; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+#ifdef CGNN_S32_ABLATE_BIAS
+            const f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#else
             const f32x4 v = *(LdsVec4Ptr)(b + 32 * t + 8 * g + 4 * h);
+#endif
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[t][4 * g + c] = v[c];
         }
 }
 
-// share [g * n / ng, (g + 1) * n / ng) of n slices for group g of ng
-constexpr int share_lo(int n, int ng, int g) { return g * n / ng; }
-constexpr int share_hi(int n, int ng, int g) { return (g + 1) * n / ng; }
-// weight-fragment reads wblock32 issues at the top of groups (g0, g1] (group x requests group x + PD)
-constexpr int frags_between(int ng, int gs, int g0, int g1) {
-    int n = 0;
-    for (int x = g0 + 1; x <= g1; ++x)
-        if (x + CGNN_S32_PD < ng) n += gs;
-    return n;
-}
-// the last group before g that ran a slice of an n-slice job (-1: none)
-constexpr int prev_share_group(int n, int ng, int g) {
-    for (int x = g - 1; x >= 0; --x)
-        if (share_hi(n, ng, x) > share_lo(n, ng, x)) return x;
+// share [q * n / nq, (q + 1) * n / nq) of n slices for slot q of nq
+constexpr int share_lo(int n, int nq, int q) { return (int)((long)q * n / nq); }
+constexpr int share_hi(int n, int nq, int q) { return (int)((long)(q + 1) * n / nq); }
+// the last slot before q that ran a slice of an n-slice job (-1: none)
+constexpr int prev_share_slot(int n, int nq, int q) {
+    for (int x = q - 1; x >= 0; --x)
+        if (share_hi(n, nq, x) > share_lo(n, nq, x)) return x;
     return -1;
 }
 
+#ifdef CGNN_S32_STAMPS   // developer build: s_memtime stamps of one workgroup's waves over one pass (printed by the launcher)
+__device__ unsigned long long cgnn_s32_stamps[4 * 64];
+#define CGNN_S32_STAMP(k)                                                                                  \
+    if (stamp_on && lane == 0) {                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        cgnn_s32_stamps[wave * 64 + (k)] = __builtin_readcyclecounter();                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    }
+#else
+#define CGNN_S32_STAMP(k)
+#endif
+
 // ---- the kernel -----------------------------------------------------------------------------------------------------
+// Schedule of one pass (= the encoder, or one round) over the wave's tile pair (A, B), nh = 2; "X.Ll" = the MFMAs of
+// layer l for tile X, "| ..." = what fills their gaps:
+//   step 0   A.P (selector MFMAs)  | LayerNorm(B) of the PREVIOUS pass, first part
+//            A.L0                  | LayerNorm(B) rest; requests for B's P rows
+//            -- barrier (next layer complete; refill of the slot the last step left) --
+//            B.P, B.L0             | refill pieces; pack(A.L0); bias of A.L1
+//   step 1   A.L1                  | pack(B.L0); bias of B.L1
+//            -- barrier --
+//            B.L1                  | refill pieces; pack(A.L1); bias of A.L2
+//   step 2   A.L2                  | pack(B.L1); bias of B.L2; requests for A's P rows of the next round
+//            -- barrier --
+//            B.L2                  | refill pieces; LayerNorm(A)
+// so every vector job runs under the other tile's MFMAs, and B's LayerNorm under the next pass's first blocks.
 template <int DT, bool ENC>
 __global__ __launch_bounds__(CGNN_S32_BLOCK, 1) void edge_stream32_kernel(
     S32Args a, const __bf16* __restrict__ ps_all, const __bf16* __restrict__ pd_all, int64_t round_stride,
@@ -478,8 +597,13 @@ __global__ __launch_bounds__(CGNN_S32_BLOCK, 1) void edge_stream32_kernel(
     const float* __restrict__ attr, int ld_attr) {
     typedef S32Geom<DT> G;
     constexpr int D = G::D, KS = G::KS;
-    typedef WBlockGroups<DT, KS> WG;
-    constexpr int NG = WG::NG;                 // MFMA groups of a full layer block
+    typedef WBlock<DT, KS> WB;
+    constexpr int MQ = WB::M;                  // MFMAs (slots) of a full layer block
+    constexpr int PQ = 4 * DT;                 // MFMAs (slots) of a P block
+    constexpr int NLN = Ln32<DT>::NS, NPACK = 2 * DT, NPL = 4 * DT;
+    // a block's pack of the other tile ends at slot QP; the other tile's next bias is requested at slot QB, several
+    // MFMAs before that tile's block begins
+    constexpr int QP = MQ >= 16 ? MQ - 12 : (MQ > 4 ? MQ - 4 : MQ), QB = MQ >= 16 ? MQ - 10 : MQ - 1;
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int L = a.rounds, nh = a.nh;
@@ -494,39 +618,46 @@ __global__ __launch_bounds__(CGNN_S32_BLOCK, 1) void edge_stream32_kernel(
     const int iters = __builtin_amdgcn_readfirstlane(
         first0 < tr.end ? (int)((tr.end - first0 + tr.stride - 1) / tr.stride) : 0);
     if (iters == 0) return;
-    VmTrack vm = {0, 0, 0};
-    Ring32<G> ring(a.image, vm, steps_per_pair, wave, lane, iters * steps_per_pair);
+    Ring32<G> ring(a.image, steps_per_pair, wave, lane);
     ring.prime();
     const bf16x8 sel0 = p32_selector(lane, 0), sel1 = p32_selector(lane, 1);
 
     Tile32<DT> A, B;
     bf16x8 ps[2 * DT], pd[2 * DT];
+    LnVec32 V;
     int64_t pair = tr.first < tr.end ? tr.first : tr.end - 1;
     bool valid = tr.first < tr.end;
 
-    auto p_issue = [&](const __bf16* tps, const __bf16* tpd, int32_t s, int32_t d, auto ic) __attribute__((always_inline)) {
-        // load i (of 4 DT): table (i & 1), piece i >> 1
+    // P-row request i (of 4 DT): table (i & 1), 16-byte piece i >> 1; `so` / `dof` = byte offsets of the lane's row halves
+    auto p_issue = [&](const __bf16* tps, const __bf16* tpd, unsigned so, unsigned dof, auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value, pc = i >> 1;
         if constexpr ((i & 1) == 0)
-            ps[pc] = p32_load<pc>(tps + (int64_t)s * D + h * (D / 2));
+            ps[pc] = p32_load<pc>(so, tps);
         else
-            pd[pc] = p32_load<pc>(tpd + (int64_t)d * D + h * (D / 2));
-        vm.op();
-        if constexpr (i == 4 * DT - 1) vm.pa = 0;
+            pd[pc] = p32_load<pc>(dof, tpd);
     };
+    auto p_issue_range = [&](const __bf16* tps, const __bf16* tpd, unsigned so, unsigned dof, auto lo_c, auto hi_c)
+                             __attribute__((always_inline)) {
+        constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
+        static_for_each([&](auto kc) __attribute__((always_inline)) {
+            constexpr int i = decltype(kc)::value + lo;
+            if constexpr (i < hi) p_issue(tps, tpd, so, dof, std::integral_constant<int, i>{});
+        }, std::make_integer_sequence<int, (hi > lo ? hi - lo : 0)>{});
+    };
+#define CGNN_IC(x) std::integral_constant<int, (x)> {}
 
     for (int it = 0; it < iters; ++it) {
-        // ---- this pair's tiles, edges and inputs (compiler-tracked loads, uncounted: once per pair) ----------------
+        // ---- this pair's tiles, edges and inputs (compiler-tracked loads: once per pair) ---------------------------
         const int64_t tA = 2 * pair, tB = (2 * pair + 1 < tiles) ? 2 * pair + 1 : 2 * pair;
         const bool validB = valid && (2 * pair + 1 < tiles);
-        int32_t sA, dA, sB, dB;
+        unsigned soA, doA, soB, doB;      // byte offsets of this lane's halves of the sender / receiver P rows
         {
             const int64_t eA = tA * 32 + r, eB = tB * 32 + r;
             const int64_t ca = eA < num_edges ? eA : num_edges - 1, cb = eB < num_edges ? eB : num_edges - 1;
-            sA = src[ca];
-            dA = dst[ca];
-            sB = src[cb];
-            dB = dst[cb];
+            soA = ((unsigned)src[ca] * (unsigned)D + (unsigned)h * (D / 2)) * 2u;
+            doA = ((unsigned)dst[ca] * (unsigned)D + (unsigned)h * (D / 2)) * 2u;
+            soB = ((unsigned)src[cb] * (unsigned)D + (unsigned)h * (D / 2)) * 2u;
+            doB = ((unsigned)dst[cb] * (unsigned)D + (unsigned)h * (D / 2)) * 2u;
             if (ENC) {
                 // lane (r, h), k-step 0, element j = edge feature 8 (j >> 2) + 4 h + (j & 3)
                 const int fin = a.enc_in_dim;
@@ -573,116 +704,160 @@ __global__ __launch_bounds__(CGNN_S32_BLOCK, 1) void edge_stream32_kernel(
         // ---- one MLP + LayerNorm pass over both tiles: nh + 1 ring steps ------------------------------------------
         // IS_ENC: the edge encoder (layer 0 = Linear of the edge features with bias, no P rows, no residual);
         // otherwise round rr (layer 0 = Ps[src] + Pd[dst] + We e).
-        // `pa_pending`: the P rows of tile A for this round were already requested (by the previous round)
-        auto pass = [&](auto enc_tag, int rr, bool pa_pending) __attribute__((always_inline)) {
+        // PEND: tile B's LayerNorm of the previous pass is still to do (0 none, 1 the encoder's, 2 a round's); its
+        // vectors sit in the ring slot of the previous step.  `pa_pending`: A's P rows were requested by that pass.
+        auto pass = [&](auto enc_tag, auto pend_tag, int rr, bool pa_pending) __attribute__((always_inline)) {
             constexpr bool IS_ENC = decltype(enc_tag)::value;
-            // the encoder's first Linear is packed with K padded to one 32-wide k tile = two k-steps, the second all zero
-            constexpr int KS0 = IS_ENC ? 2 : KS;
-            typedef WBlockGroups<DT, KS0> WG0;
-            constexpr int NG0 = WG0::NG;
+#ifdef CGNN_S32_STAMPS
+            const bool stamp_on = blockIdx.x == 8 && it == 2 && rr == 3 && !IS_ENC;
+#endif
+            CGNN_S32_STAMP(0);
+            constexpr int PEND = decltype(pend_tag)::value;
+            constexpr int KS0 = IS_ENC ? 2 : KS;     // the encoder's first Linear: K padded to one 32-wide k tile
+            typedef WBlock<DT, KS0> WB0;
+            constexpr int MQ0 = WB0::M;
             const __bf16* tps = ps_all + (int64_t)rr * round_stride;
             const __bf16* tpd = pd_all + (int64_t)rr * round_stride;
+            const unsigned pga = ring.vec_addr(-1) + (unsigned)D * 4u + 16u * (unsigned)h, pba = pga + (unsigned)D * 4u;
             // ---------------- layer 0 ----------------
             {
                 const unsigned base = ring.base();
                 if constexpr (IS_ENC) {
-                    bias_fill32<DT>(A.acc, ring.vec(), h);
+                    bias_rows32<DT, 0, DT>(A.acc, ring.vec_addr(0), h);
                     const bf16x8 (&inA)[2] = reinterpret_cast<const bf16x8(&)[2]>(A.in[0]);
-                    wblock32<DT, 2>(A.acc, inA, base, NoFill32{});
+                    wblock32<DT, 2>(A.acc, inA, base, make_fill([&](auto qc) __attribute__((always_inline)) {
+                        constexpr int q = decltype(qc)::value;
+                        if constexpr (q == MQ0 - 1) bias_rows32<DT, 0, DT>(B.acc, ring.vec_addr(0), h);
+                    }));
                 } else {
-                    if (!pa_pending)
-                        static_for_each([&](auto ic) __attribute__((always_inline)) { p_issue(tps, tpd, sA, dA, ic); },
-                                        std::make_integer_sequence<int, 4 * DT>{});
-                    vm_wait_at_most(vm.pa);
+                    // A's P rows were requested in the previous pass, before its last refill pieces; the first pass
+                    // of a pair asks for its own (the previous pair's request was for other edges)
+                    if (pa_pending) {
+                        ring.template wait_next_chunk<0>();
+                    } else {
+                        p_issue_range(tps, tpd, soA, doA, CGNN_IC(0), CGNN_IC(NPL));
+                        CGNN_S32_VMCNT(0);
+                    }
                     p32_ready<DT>(ps, pd);
-                    selp32<DT>(A.acc, ps, pd, sel0, sel1, NoFill32{});
-                    static_for_each([&](auto ic) __attribute__((always_inline)) { p_issue(tps, tpd, sB, dB, ic); },
-                                    std::make_integer_sequence<int, 4 * DT>{});
-                    wblock32<DT, KS>(A.acc, A.in, base, NoFill32{});
+                    constexpr int S1 = PEND ? NLN * PQ / (PQ + MQ) : 0;     // LayerNorm slices under the P block
+                    // B's P rows are requested as soon as A's selector MFMAs of a feature tile have read the registers
+                    // (row t's four pieces behind its fourth MFMA): a whole block ahead of their use
+                    selp32<DT>(A.acc, ps, pd, sel0, sel1, make_fill([&](auto qc) __attribute__((always_inline)) {
+                        constexpr int q = decltype(qc)::value;
+                        if constexpr (PEND != 0)
+                            ln32_run<PEND == 2, DT, share_lo(S1, PQ, q), share_hi(S1, PQ, q), 0>(B, V, pga, pba);
+                        if constexpr ((q & 3) == 3) p_issue_range(tps, tpd, soB, doB, CGNN_IC(q - 3), CGNN_IC(q + 1));
+                    }));
+                    CGNN_S32_STAMP(1);
+                    wblock32<DT, KS>(A.acc, A.in, base, make_fill([&](auto qc) __attribute__((always_inline)) {
+                        constexpr int q = decltype(qc)::value;
+                        if constexpr (PEND != 0) {
+                            constexpr int lo = S1 + share_lo(NLN - S1, MQ, q), hi = S1 + share_hi(NLN - S1, MQ, q);
+                            constexpr int qp = prev_share_slot(NLN - S1, MQ, q);
+                            ln32_run<PEND == 2, DT, lo, hi, (qp < 0 ? 0 : WB::frags_between(qp, q))>(B, V, pga, pba);
+                        }
+                    }));
                 }
-                ring.sync_next();
+                CGNN_S32_STAMP(2);
+                ring.template sync_next<IS_ENC ? 0 : NPL>();
+                CGNN_S32_STAMP(3);
                 if constexpr (IS_ENC) {
-                    bias_fill32<DT>(B.acc, ring.vec(), h);
                     const bf16x8 (&inB)[2] = reinterpret_cast<const bf16x8(&)[2]>(B.in[0]);
-                    wblock32<DT, 2>(B.acc, inB, base, make_fill([&](auto gc) __attribute__((always_inline)) {
-                        constexpr int g = decltype(gc)::value;
-                        pack32_run<true, DT, share_lo(2 * DT, NG0, g), share_hi(2 * DT, NG0, g)>(A);
-                        for (int i = share_lo(G::NP, NG0, g); i < share_hi(G::NP, NG0, g); ++i) ring.piece(i);
+                    wblock32<DT, 2>(B.acc, inB, base, make_fill([&](auto qc) __attribute__((always_inline)) {
+                        constexpr int q = decltype(qc)::value;
+                        pack32_run<true, DT, share_lo(NPACK, MQ0, q), share_hi(NPACK, MQ0, q)>(A);
+                        for (int i = share_lo(G::NP, MQ0, q); i < share_hi(G::NP, MQ0, q); ++i) ring.piece(i);
+                        if constexpr (q == MQ0 - 1) bias_rows32<DT, 0, DT>(A.acc, ring.vec_addr(1), h);
                     }));
                 } else {
-                    vm_wait_at_most(vm.pa);
+                    CGNN_S32_VMCNT(0);          // B's P rows (requested a block ago; nothing newer is in flight)
                     p32_ready<DT>(ps, pd);
-                    selp32<DT>(B.acc, ps, pd, sel0, sel1, NoFill32{});
-                    wblock32<DT, KS>(B.acc, B.in, base, make_fill([&](auto gc) __attribute__((always_inline)) {
-                        constexpr int g = decltype(gc)::value;
-                        pack32_run<true, DT, share_lo(2 * DT, NG0, g), share_hi(2 * DT, NG0, g)>(A);
-                        for (int i = share_lo(G::NP, NG0, g); i < share_hi(G::NP, NG0, g); ++i) ring.piece(i);
+                    CGNN_S32_STAMP(4);
+                    // pieces first (the P block has no LDS traffic of its own), pack(A) spread over both blocks
+                    selp32<DT>(B.acc, ps, pd, sel0, sel1, make_fill([&](auto qc) __attribute__((always_inline)) {
+                        constexpr int q = decltype(qc)::value;
+                        for (int i = share_lo(G::NP, PQ, q); i < share_hi(G::NP, PQ, q); ++i) ring.piece(i);
                     }));
+                    CGNN_S32_STAMP(5);
+                    wblock32<DT, KS>(B.acc, B.in, base, make_fill([&](auto qc) __attribute__((always_inline)) {
+                        constexpr int q = decltype(qc)::value;
+                        if constexpr (q < QP) pack32_run<true, DT, share_lo(NPACK, QP, q), share_hi(NPACK, QP, q)>(A);
+                        if constexpr (q == QB) bias_rows32<DT, 0, DT>(A.acc, ring.vec_addr(1), h);
+                    }));
+                    CGNN_S32_STAMP(6);
                 }
                 ring.dma_done();
                 ring.advance();
             }
-            // A.in = ReLU(layer 0 of A); B.acc = layer 0 of B, still to be packed
+            // A.in = ReLU(layer 0 of A), A.acc = bias of A's next layer; B.acc = layer 0 of B, still to be packed
             // ---------------- hidden layers 1 .. nh - 1 ----------------
             for (int l = 1; l < nh; ++l) {
                 const unsigned base = ring.base();
-                bias_fill32<DT>(A.acc, ring.vec(), h);
-                // B's pack reads B.acc and must be finished before B's block overwrites it: it fills A's block
-                wblock32<DT, KS>(A.acc, A.in, base, make_fill([&](auto gc) __attribute__((always_inline)) {
-                    constexpr int g = decltype(gc)::value;
-                    pack32_run<true, DT, share_lo(2 * DT, NG, g), share_hi(2 * DT, NG, g)>(B);
+                wblock32<DT, KS>(A.acc, A.in, base, make_fill([&](auto qc) __attribute__((always_inline)) {
+                    constexpr int q = decltype(qc)::value;
+                    if constexpr (q < QP) pack32_run<true, DT, share_lo(NPACK, QP, q), share_hi(NPACK, QP, q)>(B);
+                    if constexpr (q == QB) bias_rows32<DT, 0, DT>(B.acc, ring.vec_addr(0), h);
                 }));
-                ring.sync_next();
-                bias_fill32<DT>(B.acc, ring.vec(), h);
-                wblock32<DT, KS>(B.acc, B.in, base, make_fill([&](auto gc) __attribute__((always_inline)) {
-                    constexpr int g = decltype(gc)::value;
-                    pack32_run<true, DT, share_lo(2 * DT, NG, g), share_hi(2 * DT, NG, g)>(A);
-                    for (int i = share_lo(G::NP, NG, g); i < share_hi(G::NP, NG, g); ++i) ring.piece(i);
+                CGNN_S32_STAMP(7);
+                ring.template sync_next<0>();
+                CGNN_S32_STAMP(8);
+                wblock32<DT, KS>(B.acc, B.in, base, make_fill([&](auto qc) __attribute__((always_inline)) {
+                    constexpr int q = decltype(qc)::value;
+                    for (int i = share_lo(G::NP, MQ, q); i < share_hi(G::NP, MQ, q); ++i) ring.piece(i);
+                    if constexpr (q < QP) pack32_run<true, DT, share_lo(NPACK, QP, q), share_hi(NPACK, QP, q)>(A);
+                    if constexpr (q == QB) bias_rows32<DT, 0, DT>(A.acc, ring.vec_addr(1), h);
                 }));
+                CGNN_S32_STAMP(9);
                 ring.dma_done();
                 ring.advance();
             }
             // ---------------- output layer + LayerNorm (+ residual) ----------------
             {
                 const unsigned base = ring.base();
-                const LdsVecPtr vec = ring.vec();
-                const unsigned ga = base + G::VEC_OFF + (unsigned)D * 4u + 16u * (unsigned)h, ba = ga + (unsigned)D * 4u;
-                LnVec32 V;
-                bias_fill32<DT>(A.acc, vec, h);
-                wblock32<DT, KS>(A.acc, A.in, base, make_fill([&](auto gc) __attribute__((always_inline)) {
-                    constexpr int g = decltype(gc)::value;
-                    pack32_run<true, DT, share_lo(2 * DT, NG, g), share_hi(2 * DT, NG, g)>(B);
-                }));
-                ring.sync_next();
-                bias_fill32<DT>(B.acc, vec, h);
-                constexpr int NLN = Ln32<DT>::NS;
-                constexpr int COVER = (NLN * 2) / 5;      // slices of A's LayerNorm placed under B's MFMAs
+                const unsigned ga = ring.vec_addr(0) + (unsigned)D * 4u + 16u * (unsigned)h, ba = ga + (unsigned)D * 4u;
                 // the next round's P rows of tile A (the P registers are free since B's layer 0)
-                const bool next_p = IS_ENC || rr + 1 < L;
-                const __bf16* nps = IS_ENC ? ps_all : tps + round_stride;
-                const __bf16* npd = IS_ENC ? pd_all : tpd + round_stride;
-                wblock32<DT, KS>(B.acc, B.in, base, make_fill([&](auto gc) __attribute__((always_inline)) {
-                    constexpr int g = decltype(gc)::value;
-                    constexpr int gp = prev_share_group(COVER, NG, g);
-                    ln32_run<!IS_ENC, DT, share_lo(COVER, NG, g), share_hi(COVER, NG, g),
-                             frags_between(NG, WG::GS, gp < 0 ? g : gp, g)>(A, V, ga, ba);
-                    for (int i = share_lo(G::NP, NG, g); i < share_hi(G::NP, NG, g); ++i) ring.piece(i);
-                    if (next_p)
-                        static_for_each([&](auto kc) __attribute__((always_inline)) {
-                            constexpr int i = decltype(kc)::value + share_lo(4 * DT, NG, g);
-                            if constexpr (i < share_hi(4 * DT, NG, g))
-                                p_issue(nps, npd, sA, dA, std::integral_constant<int, i>{});
-                        }, std::make_integer_sequence<int, (4 * DT + NG - 1) / NG + 1>{});
+                // (the last round requests round 0's rows again: nobody reads them, but the loop stays branch-free and
+                // the wait counts constant)
+                const bool wrap = !IS_ENC && rr + 1 == L;
+                const __bf16* nps = (IS_ENC || wrap) ? ps_all : tps + round_stride;
+                const __bf16* npd = (IS_ENC || wrap) ? pd_all : tpd + round_stride;
+                wblock32<DT, KS>(A.acc, A.in, base, make_fill([&](auto qc) __attribute__((always_inline)) {
+                    constexpr int q = decltype(qc)::value;
+                    if constexpr (q < QP) pack32_run<true, DT, share_lo(NPACK, QP, q), share_hi(NPACK, QP, q)>(B);
+                    p_issue_range(nps, npd, soA, doA, CGNN_IC(share_lo(NPL, MQ, q)), CGNN_IC(share_hi(NPL, MQ, q)));
+                    if constexpr (q == QB) bias_rows32<DT, 0, DT>(B.acc, ring.vec_addr(0), h);
                 }));
+                CGNN_S32_STAMP(10);
+                ring.template sync_next<NPL>();
+                CGNN_S32_STAMP(11);
+                // pieces in the first slots, A's LayerNorm over all of them
+                wblock32<DT, KS>(B.acc, B.in, base, make_fill([&](auto qc) __attribute__((always_inline)) {
+                    constexpr int q = decltype(qc)::value;
+                    constexpr int qp = prev_share_slot(NLN, MQ, q);
+                    ln32_run<!IS_ENC, DT, share_lo(NLN, MQ, q), share_hi(NLN, MQ, q), (qp < 0 ? 0 : WB::frags_between(qp, q))>(
+                        A, V, ga, ba);
+                    for (int i = share_lo(G::NP, MQ, q); i < share_hi(G::NP, MQ, q); ++i) ring.piece(i);
+                }));
+                CGNN_S32_STAMP(12);
                 ring.dma_done();
-                ln32_run<!IS_ENC, DT, COVER, NLN, 0>(A, V, ga, ba);
-                ln32_run<!IS_ENC, DT, 0, NLN, 0>(B, V, ga, ba);
                 ring.advance();
             }
+            // pending: LayerNorm of B (its output is in B.acc, the vectors in the slot just left)
+        };
+        auto flush_ln_b = [&](auto res_tag) __attribute__((always_inline)) {
+            const unsigned pga = ring.vec_addr(-1) + (unsigned)D * 4u + 16u * (unsigned)h, pba = pga + (unsigned)D * 4u;
+            ln32_run<decltype(res_tag)::value, DT, 0, NLN, 0>(B, V, pga, pba);
         };
 
-        if (ENC) pass(std::true_type{}, 0, false);
-        for (int rr = 0; rr < L; ++rr) pass(std::false_type{}, rr, ENC || rr > 0);
+        if (ENC) {
+            pass(std::true_type{}, CGNN_IC(0), 0, false);
+            pass(std::false_type{}, CGNN_IC(1), 0, true);
+            for (int rr = 1; rr < L; ++rr) pass(std::false_type{}, CGNN_IC(2), rr, true);
+        } else {
+            pass(std::false_type{}, CGNN_IC(0), 0, false);
+            for (int rr = 1; rr < L; ++rr) pass(std::false_type{}, CGNN_IC(2), rr, true);
+        }
+        flush_ln_b(std::true_type{});
 
         auto store_latent = [&](const Tile32<DT>& X, int64_t T) __attribute__((always_inline)) {
             f32x16 v[DT];
@@ -701,6 +876,9 @@ __global__ __launch_bounds__(CGNN_S32_BLOCK, 1) void edge_stream32_kernel(
             valid = false;
         }
     }
+    CGNN_S32_VMCNT(0);      // the ring's last refills (unread) must have landed before the workgroup's LDS is released
+    __builtin_amdgcn_s_barrier();
+#undef CGNN_IC
 }
 
 template <int DT>
@@ -719,6 +897,24 @@ static int launch_stream32(const S32Args& a, const __bf16* ps, const __bf16* pd,
     const int64_t pairs = ((num_edges + 31) / 32 + 1) / 2;
     const int grid = grid_for_tiles(pairs, 1, CGNN_S32_WAVES);
     kern<<<grid, CGNN_S32_BLOCK, G::LDS, st>>>(a, ps, pd, round_stride, src, dst, num_edges, e_in, e_out, attr, ld_attr);
+#ifdef CGNN_S32_STAMPS
+    {
+        static int printed = 0;
+        hipStreamSynchronize(st);
+        if (printed++ == 2) {
+            static unsigned long long hs[4 * 64];
+            hipMemcpyFromSymbol(hs, HIP_SYMBOL(cgnn_s32_stamps), sizeof(hs));
+            const char* names[13] = {"start", "A.P done", "A.L0 done", "barrier0", "B rows ready", "B.P done", "B.L0 done",
+                                     "A.L1 done", "barrier1", "B.L1 done", "A.L2 done", "barrier2", "B.L2 done"};
+            for (int k = 0; k < 13; ++k) {
+                printf("stamp %2d %-14s", k, names[k]);
+                for (int w = 0; w < 4; ++w) printf(" %7lld (+%5lld)", (long long)(hs[w * 64 + k] - hs[0]),
+                                                   k ? (long long)(hs[w * 64 + k] - hs[w * 64 + k - 1]) : 0LL);
+                printf("\n");
+            }
+        }
+    }
+#endif
     return check_hip(hipGetLastError(), "cgnn_edge_stream_run launch");
 }
 
