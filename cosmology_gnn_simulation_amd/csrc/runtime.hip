@@ -298,6 +298,83 @@ __global__ void aggregate_atomic_kernel(const float* __restrict__ table, int tab
     atomicAdd(o + 3, acc[3]);
 }
 
+
+// General edge list, the shape the float-atomic unit wants (MI355X: about 1.3 TB/s of added bytes chip-wide, reached
+// only when ONE wave instruction adds 256 contiguous bytes, or two 128-byte segments; a 16-byte lane stride is several
+// times slower).  LPR = width / 4 lanes share a row (16 bytes per lane: the efficient load shape), so a wave walks
+// 64 / LPR contiguous edge ranges at once.
+//  1. run-length reduction in registers: consecutive edges with the same destination (every edge of a receiver in a
+//     receiver-sorted list) are summed before anything is added to memory;
+//  2. a flush goes through a 1-KiB LDS block per wave, written row by row (16 bytes per lane) and read back dword by
+//     dword, so that every atomic wave instruction covers 64 consecutive floats of one row (32 consecutive floats of
+//     two rows at width 32): the full-rate shape;
+//  3. four edges per step: their indices and rows are requested before the first add.
+// Sum order inside a run is the list order; across runs it is the atomics' arrival order (not reproducible).
+template <int LPR>
+__global__ __launch_bounds__(CGNN_BLOCK) void aggregate_scatter_kernel(const float* __restrict__ table, int table_tiled,
+                                                                       const int32_t* __restrict__ gather,
+                                                                       const int32_t* __restrict__ dst, int64_t num_edges,
+                                                                       int edges_per_group, float* __restrict__ out) {
+    constexpr int GPW = 64 / LPR;          // groups (= edge ranges) per wave
+    constexpr int W = 4 * LPR;             // row width in floats
+    constexpr int U = 4;
+    __shared__ __attribute__((aligned(16))) float stage[CGNN_WAVES_PER_BLOCK][256];
+    __shared__ int stage_dst[CGNN_WAVES_PER_BLOCK][GPW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane / LPR, c = lane % LPR;
+    const int64_t group = ((int64_t)blockIdx.x * CGNN_WAVES_PER_BLOCK + wave) * GPW + g;
+    const int64_t e0 = group * edges_per_group;
+    int64_t e1 = e0 + edges_per_group < num_edges ? e0 + edges_per_group : num_edges;
+    if (e1 < e0) e1 = e0;
+    // every group of the wave runs the same number of steps (the flush is a wave-wide exchange)
+    const int steps = (edges_per_group + U - 1) / U;
+    int cur = e0 < num_edges ? dst[e0] : -1;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto flush = [&](bool mine) {      // `mine`: this lane's group hands its sum over (wave-uniform call)
+        *reinterpret_cast<f32x4*>(&stage[wave][lane * 4]) = mine ? acc : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c == 0) stage_dst[wave][g] = mine ? cur : -1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = j * 64 + lane;                 // dword x of the block = row x / W, column x % W
+            const int d = stage_dst[wave][x / W];
+            if (d >= 0) atomicAdd(out + (int64_t)d * W + (x % W), stage[wave][x]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (mine) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    for (int s = 0; s < steps; ++s) {
+        const int64_t eb = e0 + (int64_t)s * U;
+        int d[U];
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t e = eb + u;
+            d[u] = e < e1 ? dst[e] : -2;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t e = eb + u;
+            if (e < e1) {
+                const int64_t idx = gather ? (int64_t)gather[e] : e;
+                v[u] = *reinterpret_cast<const f32x4*>(table + (table_tiled ? tiled_chunk_offset(idx, c, LPR)
+                                                                            : (idx * LPR + c) * 4));
+            } else {
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool change = d[u] != -2 && d[u] != cur;
+            if (__any(change)) flush(change);
+            if (change) cur = d[u];
+            acc += v[u];
+        }
+    }
+    if (__any(cur >= 0)) flush(cur >= 0);
+}
+
 // ------------------------------------------------------------------ rows
 __global__ void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ idx, int64_t n_idx,
                                    int chunks, float* __restrict__ out) {
@@ -562,6 +639,22 @@ int cgnn_aggregate(const float* table, int32_t table_layout, const int32_t* gath
     }
     int rc = check_hip(hipMemsetAsync(out, 0, (size_t)num_nodes * width * sizeof(float), st), "cgnn_aggregate memset");
     if (rc != CGNN_OK || num_edges == 0) return rc;
+    if (chunks == 8 || chunks == 16 || chunks == 32 || chunks == 64) {
+        // widths 32 / 64 / 128 / 256: contiguous 256-byte atomic instructions (aggregate_scatter_kernel)
+        const int epg = 32;
+        const int gpw = 64 / chunks;
+        const int64_t groups = (num_edges + epg - 1) / epg;
+        const int64_t waves = (groups + gpw - 1) / gpw;
+        const int64_t blocks = (waves + CGNN_WAVES_PER_BLOCK - 1) / CGNN_WAVES_PER_BLOCK;
+#define CGNN_SCATTER(LPR) \
+    aggregate_scatter_kernel<LPR><<<(unsigned)blocks, CGNN_BLOCK, 0, st>>>(table, tiled, gather, dst, num_edges, epg, out)
+        if (chunks == 8) CGNN_SCATTER(8);
+        else if (chunks == 16) CGNN_SCATTER(16);
+        else if (chunks == 32) CGNN_SCATTER(32);
+        else CGNN_SCATTER(64);
+#undef CGNN_SCATTER
+        return check_hip(hipGetLastError(), "cgnn_aggregate(scatter) launch");
+    }
     const int epg = 16;
     const int64_t groups = (num_edges + epg - 1) / epg;
     const int64_t threads = groups * chunks;

@@ -91,6 +91,17 @@ if a.edge_precision == "bf16" and (not a.only or a.only.startswith("edge_stream"
 t("edge_block", lambda: ops.edge_block(p.edge, ps, pd, src, dst, e, e, None, True),
   2 * E * d * 4 + 2 * E * 4 + 2 * n * d * 4, 6.0 * E * d * d)
 t("aggregate x_j", lambda: ops.aggregate(x, src, dst, n, fk, E, agg), E * d * 4 + E * 4 + n * d * 4)
+# general scatter-add (fixed_k = 0): receiver-sorted list (one atomic row per receiver) and a shuffled one (one per edge);
+# GB/s = table rows read + atomic bytes added
+if not a.only or a.only == "aggregate_atomic":
+    perm = torch.randperm(E, device=dev)
+    src_sh, dst_sh = src[perm].contiguous(), dst[perm].contiguous()
+    _o = a.only
+    a.only = None
+    t("scatter sorted", lambda: ops.aggregate(x, src, dst, n, 0, E, agg), E * d * 4 + E * 8 + n * d * 4)
+    t("scatter shuffled", lambda: ops.aggregate(x, src_sh, dst_sh, n, 0, E, agg), E * d * 4 + E * 8 + E * d * 4)
+    print(f"   (shuffled: {E * d * 4 / 1e9:.2f} GB of float atomics per call)")
+    a.only = _o
 t("node_block", lambda: ops.node_block(p.node, p.wx, p.wa, x, agg, x, True), 3 * n * d * 4, 8.0 * n * d * d)
 if len(roundsL) > 1 and roundsL[0].node.precision == 4:      # F32X3_N16: projections of the next round fused in
     q_ = roundsL[1]

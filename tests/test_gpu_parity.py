@@ -84,8 +84,13 @@ def test_aggregate_fixed_k_is_exact_segment_sum(n, k, width):
 
 
 @pytest.mark.parametrize("n,e,width,sorted_dst", [(500, 8000, 128, True), (500, 8000, 64, False), (10, 0, 32, True),
-                                                  (7, 1, 32, False)])
+                                                  (7, 1, 32, False), (2000, 50001, 256, False), (3, 1000, 32, False),
+                                                  (40000, 333333, 128, True), (999, 31, 128, False), (64, 5000, 36, False),
+                                                  (5000, 80000, 64, True)])
 def test_aggregate_general_edge_list(n, e, width, sorted_dst):
+    """General scatter-add (fixed_k = 0): widths 32 / 64 / 128 / 256 take the contiguous-atomic kernel (run-length
+    reduction + LDS-transposed 256-byte atomic instructions), other widths the scalar-atomic one; destinations with
+    thousands of contributions (n = 3), partial last groups, empty lists."""
     gen = torch.Generator().manual_seed(e + 1)
     x = torch.randn(n, width, generator=gen)
     src = torch.randint(0, n, (e,), generator=gen)
