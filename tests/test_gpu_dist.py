@@ -14,9 +14,21 @@ W = 5
                                             (8, "edge", "fp32"), (2, "x_j", "bf16"), (8, "x_j", "bf16")])
 def test_sharded_forward_equals_unsharded(world, msg, prec):
     """prec "bf16" = bench.py's configuration (bf16 edge MLP, three-term node path): in x_j mode every rank runs its
-    node stream round by round (halo per round) and then ONE cgnn_edge_stream launch, as the single-GPU forward does."""
-    n, k, d, L = 6000, 16, 64, 3
-    snap = synthetic.make_snapshot(n, seed=41)
+    node stream round by round (halo per round) and then ONE one-launch edge stream, as the single-GPU forward does."""
+    _sharded_vs_unsharded(6000, 16, 64, 3, world, msg, prec, seed=41)
+
+
+@pytest.mark.parametrize("name,n,k,d,L,seed", [("cfg4", 4_000_000, 16, 128, 10, 1238), ("cfg5", 1_000_000, 32, 256, 15, 1239)])
+def test_baseline_multi_gpu_configs_through_the_loopback_shards(name, n, k, d, L, seed):
+    """BASELINE cfg4 (4 M particles, k = 16, latent 128, 10 rounds) and cfg5 (1 M, k = 32, latent 256, 15 rounds), both
+    quoted on 8 x MI355X, at their FULL size: the eight spatial tiles run one after the other on this GPU with the halo
+    as device-to-device copies, in the order ShardedForward uses, and every tile's owned rows must equal the unsharded
+    forward bit for bit (node outputs and node latents); one tile's edge latents are compared as well."""
+    _sharded_vs_unsharded(n, k, d, L, 8, "x_j", "bf16", seed=seed, full_size=True)
+
+
+def _sharded_vs_unsharded(n, k, d, L, world, msg, prec, seed, full_size=False):
+    snap = synthetic.make_snapshot(n, seed=seed)
     meta = synthetic.make_metadata()
     g = data_utils.preprocess(snap["Coordinates"][:W], snap["InternalEnergy"][:W], meta, None, None, 0.0, k, 0.01, 1.0)
     model = graph_network.EncodeProcessDecode(d, d, 2, L, 3)
@@ -27,8 +39,11 @@ def test_sharded_forward_equals_unsharded(world, msg, prec):
         model.edge_precision, model.node_precision = "bf16", "fp32x3"
     with torch.no_grad():
         want = model.forward_with_latents(g)
-
     shards = [cdist.build_shard(g.pos, 1.0, k, world, r) for r in range(world)]
+    if full_size:
+        own0 = shards[0].owned_global
+        want["edge_latent"] = want["edge_latent"].view(n, k, -1)[own0].reshape(-1, want["edge_latent"].shape[1]).clone()
+        torch.cuda.empty_cache()
     for r, sh in enumerate(shards):
         cdist.finish_shard(sh, [shards[p].want_global[r] for p in range(world)])
         sh.x_feat = g.x[sh.owned_global].contiguous()
@@ -66,10 +81,16 @@ def test_sharded_forward_equals_unsharded(world, msg, prec):
                 for rn in runners:
                     rn.round(i)
         outs = [rn.decode() for rn in runners]
-    assert all(rn.fused == (prec == "bf16" and msg == "x_j") for rn in runners)
-    for sh, o, rn in zip(shards, outs, runners):
+    assert all(rn.fused == (prec == "bf16" and msg == "x_j" and d <= 128) for rn in runners)
+    for r, (sh, o, rn) in enumerate(zip(shards, outs, runners)):
         assert torch.equal(o["acceleration"], want["acceleration"][sh.owned_global])
         assert torch.equal(o["temp_rate"], want["temp_rate"][sh.owned_global])
+        assert torch.equal(rn.x_all[:sh.n_owned], want["x_latent"][sh.owned_global])
+        if full_size:
+            if r == 0:
+                got_e = rn.el.to_rows()
+                assert float((got_e - want["edge_latent"]).norm() / want["edge_latent"].norm()) <= 2e-2
+            continue
         # the owned receivers' edge latents: ghost senders' projections come from the stand-alone projection kernel
         # (different f32 summation order before the bf16 rounding than the node kernel's epilogue), so these agree to
         # bf16 rounding, not bit for bit
