@@ -13,8 +13,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# CGNN_LIB_PATH: developer override (A/B timing of two builds on one GPU box); the product loads the in-tree library
-LIB_PATH = os.environ.get("CGNN_LIB_PATH") or os.path.join(_HERE, "libcgnn_hip.so")
+# the in-tree library (developer scripts that compare two builds assign another path before the first load())
+LIB_PATH = os.path.join(_HERE, "libcgnn_hip.so")
 
 MAX_HIDDEN_LAYERS = 6
 F32, BF16, BF16_N16, F32X3, F32X3_N16 = 0, 1, 2, 3, 4  # cgnn_precision

@@ -465,14 +465,10 @@ static int launch_stream(const StreamArgs& a, size_t lds, const __bf16* ps, cons
                          const int32_t* src, const int32_t* dst, int64_t num_edges, const float* e_in, float* e_out,
                          const float* attr, int ld_attr, hipStream_t st) {
     // P rows through the matrix pipe (measured 24.2 ms against 28.1 ms through the vector pipe at cfg3: the loop is
-    // bound by vector issue).  CGNN_STREAM_PMFMA=0 selects the vector form (developer A/B).
-    static const bool pmfma = [] {
-        const char* v = getenv("CGNN_STREAM_PMFMA");
-        return !(v && atoi(v) == 0);
-    }();
+    // bound by vector issue)
+    constexpr bool pmfma = true;
     const bool enc = a.enc_layers > 0;
-    auto kern = enc ? edge_stream_n16_kernel<HT, DT, true, true>
-                    : (pmfma ? edge_stream_n16_kernel<HT, DT, true, false> : edge_stream_n16_kernel<HT, DT, false, false>);
+    auto kern = enc ? edge_stream_n16_kernel<HT, DT, pmfma, true> : edge_stream_n16_kernel<HT, DT, pmfma, false>;
     if (lds > 48 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),

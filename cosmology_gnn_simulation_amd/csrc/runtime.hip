@@ -22,17 +22,19 @@ int check_hip(hipError_t e, const char* what) {
     return CGNN_ERR_HIP;
 }
 
-static int g_num_cu = 0;
+// compute units of the CURRENT device (the one the caller's stream belongs to), cached per device
+static int g_num_cu[64] = {0};
 
 static int num_cus() {
-    if (g_num_cu == 0) {
-        int dev = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (g_num_cu[dev] == 0) {
         hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
-            g_num_cu = p.multiProcessorCount;
-        if (g_num_cu <= 0) g_num_cu = 256;
+        int n = 0;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        g_num_cu[dev] = n > 0 ? n : 256;
     }
-    return g_num_cu;
+    return g_num_cu[dev];
 }
 
 // One wave owns one 32-row tile at a time; blocks are persistent (grid-stride).

@@ -201,9 +201,10 @@ def preprocess(position_seq, temperature_seq, metadata, target_position=None, ta
         y_acc=acceleration.float() if acceleration is not None else None,
         y_temp_rate=temp_rate.float() if temp_rate is not None else None,
         pos=recent_position,
-        dt=torch.tensor([dt], dtype=torch.float32, device=device),
-        box_size=torch.tensor([box_size], dtype=torch.float32, device=device),
+        dt=torch.full((1,), dt, dtype=torch.float32, device=device),            # (a fill kernel: torch.tensor([dt],
+        box_size=torch.full((1,), box_size, dtype=torch.float32, device=device),  # device=...) would synchronise)
     )
     graph._cgnn_fixed_k = int(num_neighbors)
+    graph._cgnn_fixed_k_for = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape))
     graph._cgnn_order = order          # spatial (cell-sorted) particle order: a locality hint for the engine
     return graph

@@ -91,9 +91,15 @@ class Batch(Data):
                                for i, g in enumerate(graphs)])
         out.num_graphs = len(graphs)
         # engine hints survive when every member has the same fixed in-degree
-        ks = {getattr(g, "_cgnn_fixed_k", None) for g in graphs}
+        # (a member's hint counts only while it is bound to the member's own edge_index, see _graph_arrays)
+        def bound(g):
+            ei = getattr(g, "edge_index", None)
+            return torch.is_tensor(ei) and getattr(g, "_cgnn_fixed_k_for", None) == (ei.data_ptr(), ei._version, tuple(ei.shape))
+        ks = {getattr(g, "_cgnn_fixed_k", None) if bound(g) else None for g in graphs}
         if len(ks) == 1 and None not in ks:
             out._cgnn_fixed_k = ks.pop()
+            ei = out.edge_index
+            out._cgnn_fixed_k_for = (ei.data_ptr(), ei._version, tuple(ei.shape))
         orders = [getattr(g, "_cgnn_order", None) for g in graphs]
         if all(o is not None for o in orders):
             out._cgnn_order = torch.cat([o + off for o, off in zip(orders, offsets)])

@@ -123,7 +123,9 @@ def _graph_arrays(data, num_nodes: int):
     ne = ei.shape[1]
     fixed_k = 0
     hint = getattr(data, "_cgnn_fixed_k", None)
-    if hint is not None and num_nodes * int(hint) == ne:
+    # the hint is only trusted for the edge_index it was computed for (preprocess binds it): a caller that replaces or
+    # reorders the edges of a preprocessed graph (same size, other order) gets the one-off layout check instead
+    if hint is not None and num_nodes * int(hint) == ne and getattr(data, "_cgnn_fixed_k_for", None) == key:
         fixed_k = int(hint)
     elif num_nodes > 0 and ne > 0 and ne % num_nodes == 0:
         k = ne // num_nodes
@@ -132,6 +134,8 @@ def _graph_arrays(data, num_nodes: int):
             fixed_k = k
     try:
         data._cgnn_graph = (key, src, dst, fixed_k)
+        if fixed_k:
+            data._cgnn_fixed_k, data._cgnn_fixed_k_for = fixed_k, key
     except Exception:  # foreign Data types may refuse private attributes
         pass
     return src, dst, fixed_k
@@ -201,7 +205,7 @@ class GraphIndependent(nn.Module):
         out = Data(x=new_x, edge_index=data.edge_index, edge_attr=new_e)
         if hasattr(data, "globals"):
             out.globals = data.globals
-        for hint in ("_cgnn_fixed_k", "_cgnn_graph"):
+        for hint in ("_cgnn_fixed_k", "_cgnn_fixed_k_for", "_cgnn_graph"):
             if hasattr(data, hint):
                 setattr(out, hint, getattr(data, hint))
         return out
@@ -362,7 +366,7 @@ class InteractionNetwork(nn.Module):
         out = Data(x=new_x, edge_index=data.edge_index, edge_attr=new_e.to_rows())
         if hasattr(data, "globals"):
             out.globals = data.globals
-        for hint in ("_cgnn_fixed_k", "_cgnn_graph"):
+        for hint in ("_cgnn_fixed_k", "_cgnn_fixed_k_for", "_cgnn_graph"):
             if hasattr(data, hint):
                 setattr(out, hint, getattr(data, hint))
         return out
@@ -470,6 +474,17 @@ class EncodeProcessDecode(nn.Module):
             + 12 * 64
         return (enc.num_hidden_layers == e0.num_hidden_layers and enc.hidden == e0.hidden and enc.out_dim == latent and
                 enc.in_dim <= 32 and (len(rounds) + 1) * (e0.num_hidden_layers + 1) <= 64 and lds <= 160 * 1024)
+
+    def invalidate_packed(self) -> None:
+        """Forget the MFMA-packed copies of the weights.  They are rebuilt when a parameter tensor is replaced or
+        modified in place THROUGH autograd-visible operations (``optimizer.step()``, ``load_state_dict``, ``p.copy_``):
+        the cache is keyed on ``(data_ptr, _version)``.  Updates made through ``param.data`` (``p.data.mul_()``, EMA /
+        SWA averaging, some initialisers) do not bump that version: call this afterwards."""
+        self._packed = None
+        self._train_packed = None
+        self.encoder._packed = None
+        for net in self.processor:
+            net._packed = None
 
     # -- forward ---------------------------------------------------------------
     def forward(self, input_graph) -> dict:

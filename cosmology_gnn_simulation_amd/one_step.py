@@ -32,17 +32,28 @@ def load_model(model_path: str, args) -> EncodeProcessDecode:
     return model
 
 
+def integration_constants(metadata: dict, device) -> dict:
+    """The four un-normalisation statistics as device tensors, made ONCE: building them inside the step would cost a
+    blocking host-to-device copy (= a stream synchronisation) per statistic and step."""
+    out = {}
+    for key in ("acc_std", "acc_mean", "temp_rate_std", "temp_rate_mean"):
+        host = torch.tensor(metadata[key], dtype=torch.float32)
+        if torch.device(device).type == "cuda":     # pinned + non_blocking: no stream synchronisation
+            host = host.pin_memory()
+        out[key] = host.to(device, non_blocking=True)
+    return out
+
+
 def integrate_one_step(acc_pred: torch.Tensor, temp_rate_pred: torch.Tensor, coords_seq: torch.Tensor,
-                       temp_seq: torch.Tensor, metadata: dict):
-    """Un-normalise the predictions and advance one step (reference one_step_test.py:84-105)."""
+                       temp_seq: torch.Tensor, metadata: dict, consts: dict = None):
+    """Un-normalise the predictions and advance one step (reference one_step_test.py:84-105).  ``consts``:
+    :func:`integration_constants` of the same metadata (made here when omitted)."""
     dev = acc_pred.device
     dt, box = metadata["dt"], metadata["box_size"]
-
-    def m(key):
-        return torch.tensor(metadata[key], dtype=torch.float32, device=dev)
-
-    acc = acc_pred * m("acc_std") + m("acc_mean")
-    rate = temp_rate_pred * m("temp_rate_std") + m("temp_rate_mean")
+    if consts is None:
+        consts = integration_constants(metadata, dev)
+    acc = acc_pred * consts["acc_std"] + consts["acc_mean"]
+    rate = temp_rate_pred * consts["temp_rate_std"] + consts["temp_rate_mean"]
     recent_p = coords_seq[-1].to(dev)
     recent_v = (recent_p - coords_seq[-2].to(dev)) / dt
     new_v = recent_v + acc * dt

@@ -42,10 +42,19 @@ class OpTimer:
 
 
 class _timed:
+    """Launch context of one op: makes the tensors' device the current HIP device for the duration of the call (the
+    library launches on the current device and sets kernel attributes there; the stream handed over belongs to this
+    device) and, under an :class:`OpTimer`, brackets the call with events on the launch stream."""
+
     def __init__(self, name: str, device):
-        self.name, self.device = name, device
+        self.name, self.device = name, torch.device(device)
+        self.guard = None
 
     def __enter__(self):
+        if self.device.type == "cuda" and self.device.index is not None and \
+                self.device.index != torch.cuda.current_device():
+            self.guard = torch.cuda.device(self.device)
+            self.guard.__enter__()
         if _timer is not None:
             self.a = torch.cuda.Event(enable_timing=True)
             self.b = torch.cuda.Event(enable_timing=True)
@@ -55,7 +64,17 @@ class _timed:
         if _timer is not None:
             self.b.record(torch.cuda.current_stream(self.device))
             _timer.records.setdefault(self.name, []).append((self.a, self.b))
+        if self.guard is not None:
+            self.guard.__exit__(*exc)
+            self.guard = None
         return False
+
+
+def _same_device(*tensors):
+    """All tensor arguments of one op must live on one device."""
+    devs = {t.device for t in tensors if t is not None and torch.is_tensor(t)}
+    if len(devs) > 1:
+        raise CgnnError(f"tensors of one op live on different devices: {sorted(str(d) for d in devs)}")
 
 
 def _prec(p) -> int:
@@ -80,8 +99,9 @@ class PackedLinear:
         self.in_dim, self.out_dim = int(ncols), int(out_dim)
         nbytes = lib.cgnn_packed_linear_bytes(out_dim, ncols, self.precision)
         self.packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-        check(lib.cgnn_pack_linear(w.data_ptr(), out_dim, ld, col0, ncols, self.precision, self.packed.data_ptr(),
-                                   stream_ptr(w.device)), "cgnn_pack_linear")
+        with _timed("pack_linear", w.device):
+            check(lib.cgnn_pack_linear(w.data_ptr(), out_dim, ld, col0, ncols, self.precision, self.packed.data_ptr(),
+                                       stream_ptr(w.device)), "cgnn_pack_linear")
         self.bias = None if bias is None else f32c(bias.detach(), "bias").clone()
 
     def struct(self) -> Linear:
@@ -166,14 +186,16 @@ def relayout(x):
     if isinstance(x, TiledRows):
         out = torch.empty((x.n, x.width), dtype=torch.float32, device=x.device)
         if x.n:
-            check(lib.cgnn_relayout(x.buf.data_ptr(), _lib.TILED32, out.data_ptr(), _lib.ROWS, x.n, x.width,
-                                    stream_ptr(x.device)), "cgnn_relayout")
+            with _timed("relayout", x.device):
+                check(lib.cgnn_relayout(x.buf.data_ptr(), _lib.TILED32, out.data_ptr(), _lib.ROWS, x.n, x.width,
+                                        stream_ptr(x.device)), "cgnn_relayout")
         return out
     x = f32c(x, "x")
     t = TiledRows(x.shape[0], x.shape[1], x.device)
     if t.n:
-        check(lib.cgnn_relayout(x.data_ptr(), _lib.ROWS, t.buf.data_ptr(), _lib.TILED32, t.n, t.width,
-                                stream_ptr(x.device)), "cgnn_relayout")
+        with _timed("relayout", x.device):
+            check(lib.cgnn_relayout(x.data_ptr(), _lib.ROWS, t.buf.data_ptr(), _lib.TILED32, t.n, t.width,
+                                    stream_ptr(x.device)), "cgnn_relayout")
     return t
 
 
@@ -262,6 +284,7 @@ def edge_block(mlp: PackedMLP, ps: torch.Tensor, pd: torch.Tensor, src: torch.Te
                 raise CgnnError("edge_block: x_gather width must equal the latent size")
         if agg_out.dtype != torch.float32 or not agg_out.is_contiguous() or agg_out.shape[1] != latent:
             raise CgnnError("edge_block: agg_out must be contiguous float32 [receivers, latent]")
+    _same_device(ps, pd, src, dst, e_in.buf, e_out.buf, x_gather, agg_out)
     with _timed("edge_block", e_in.device):
         check(_lib.load().cgnn_edge_block(C.byref(mlp.struct()), ps.data_ptr(), pd.data_ptr(), src.data_ptr(),
                                           dst.data_ptr(), ne, e_in.buf.data_ptr(), e_out.buf.data_ptr(),
@@ -400,6 +423,7 @@ def aggregate(table, gather: Optional[torch.Tensor], dst: Optional[torch.Tensor]
         num_edges = gather.numel() if gather is not None else (dst.numel() if dst is not None else nrows)
     if out is None:
         out = torch.empty((num_nodes, width), dtype=torch.float32, device=dev)
+    _same_device(tb, gather, dst, out)
     with _timed("aggregate", dev):
         check(_lib.load().cgnn_aggregate(tb.data_ptr(), layout, ptr(gather), ptr(dst), num_edges, fixed_k, num_nodes,
                                          width, out.data_ptr(), stream_ptr(dev)), "cgnn_aggregate")
@@ -426,6 +450,7 @@ def node_block(mlp: PackedMLP, w_x: PackedLinear, w_agg: PackedLinear, x: torch.
         proj = (C.byref(s1), C.byref(s2), ws.precision, ps.data_ptr(), pd.data_ptr(), p_format)
     else:
         proj = (None, None, 0, None, None, 0)
+    _same_device(x, agg, x_out)
     with _timed("node_block", x.device):
         check(_lib.load().cgnn_node_block(C.byref(mlp.struct()), C.byref(sx), C.byref(sa), x.data_ptr(), agg.data_ptr(),
                                           n, x_out.data_ptr(), 1 if residual else 0, latent, *proj,
@@ -483,11 +508,13 @@ def window_features(pos_seq: torch.Tensor, temp_seq: torch.Tensor, metadata: dic
             raise CgnnError("window_features: noise must be [N, W, 3] / [N, W(, 1)]")
     x = torch.empty((n, 3 * (w - 1) + w), dtype=torch.float32, device=pos_seq.device)
     recent = torch.empty((n, 3), dtype=torch.float32, device=pos_seq.device)
-    check(_lib.load().cgnn_window_features(pos_seq.data_ptr(), temp_seq.data_ptr(), ptr(pos_noise), ptr(temp_noise), w, n,
-                                           float(box_size), float(dt), scalar(metadata["vel_mean"]),
-                                           scalar(metadata["vel_std"]), scalar(metadata["temp_mean"]),
-                                           scalar(metadata["temp_std"]), x.data_ptr(), recent.data_ptr(),
-                                           stream_ptr(pos_seq.device)), "cgnn_window_features")
+    _same_device(pos_seq, temp_seq, pos_noise, temp_noise)
+    with _timed("window_features", pos_seq.device):
+        check(_lib.load().cgnn_window_features(pos_seq.data_ptr(), temp_seq.data_ptr(), ptr(pos_noise), ptr(temp_noise), w, n,
+                                               float(box_size), float(dt), scalar(metadata["vel_mean"]),
+                                               scalar(metadata["vel_std"]), scalar(metadata["temp_mean"]),
+                                               scalar(metadata["temp_std"]), x.data_ptr(), recent.data_ptr(),
+                                               stream_ptr(pos_seq.device)), "cgnn_window_features")
     return x, recent
 
 
@@ -497,8 +524,10 @@ def segment_colsum(acc: torch.Tensor, batch: Optional[torch.Tensor], num_graphs:
         batch = i32c(batch, "batch")
     n, width = acc.shape
     sums = torch.empty((num_graphs, width), dtype=torch.float64, device=acc.device)
-    check(_lib.load().cgnn_segment_colsum(acc.data_ptr(), ptr(batch), n, width, num_graphs, sums.data_ptr(),
-                                          stream_ptr(acc.device)), "cgnn_segment_colsum")
+    _same_device(acc, batch)
+    with _timed("segment_colsum", acc.device):
+        check(_lib.load().cgnn_segment_colsum(acc.data_ptr(), ptr(batch), n, width, num_graphs, sums.data_ptr(),
+                                              stream_ptr(acc.device)), "cgnn_segment_colsum")
     return sums
 
 
@@ -506,8 +535,10 @@ def gather_rows(table: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tens
     table, idx = f32c(table, "table"), i32c(idx, "idx")
     if out is None:
         out = torch.empty((idx.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
-    check(_lib.load().cgnn_gather_rows(table.data_ptr(), idx.data_ptr(), idx.numel(), table.shape[1], out.data_ptr(),
-                                       stream_ptr(table.device)), "cgnn_gather_rows")
+    _same_device(table, idx, out)
+    with _timed("gather_rows", table.device):
+        check(_lib.load().cgnn_gather_rows(table.data_ptr(), idx.data_ptr(), idx.numel(), table.shape[1], out.data_ptr(),
+                                           stream_ptr(table.device)), "cgnn_gather_rows")
     return out
 
 
@@ -516,8 +547,10 @@ def scatter_rows(rows: torch.Tensor, idx: torch.Tensor, table: torch.Tensor) -> 
     require_device(table, "table")
     if not table.is_contiguous() or table.dtype != torch.float32:
         raise CgnnError("scatter_rows: table must be contiguous float32")
-    check(_lib.load().cgnn_scatter_rows(rows.data_ptr(), idx.data_ptr(), idx.numel(), table.shape[1],
-                                        table.data_ptr(), stream_ptr(table.device)), "cgnn_scatter_rows")
+    _same_device(rows, idx, table)
+    with _timed("scatter_rows", table.device):
+        check(_lib.load().cgnn_scatter_rows(rows.data_ptr(), idx.data_ptr(), idx.numel(), table.shape[1],
+                                            table.data_ptr(), stream_ptr(table.device)), "cgnn_scatter_rows")
     return table
 
 

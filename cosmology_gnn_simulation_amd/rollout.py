@@ -5,7 +5,9 @@ Per step the reference rebuilds the k-NN graph on the CPU, moves it to the GPU, 
 the model, copies the predictions back, integrates on the CPU and grows the
 trajectory with ``torch.cat`` (O(T^2) copies, :84-85).  Here the trajectory is a
 pre-allocated device buffer and graph build -> forward -> integrate -> wrap never
-leave the GPU; the number of neighbours is a parameter (hard-coded 16 at :49).
+leave the GPU: after the first step (weight packing) a step contains no host
+synchronisation at all (tests run it under ``torch.cuda.set_sync_debug_mode("error")``);
+the number of neighbours is a parameter (hard-coded 16 at :49).
 """
 from __future__ import annotations
 
@@ -14,7 +16,7 @@ from typing import Dict, Optional
 import torch
 
 from .data_utils import preprocess
-from .one_step import integrate_one_step
+from .one_step import integrate_one_step, integration_constants
 
 
 def rollout(model, data: Dict[str, torch.Tensor], metadata: dict, noise_std: float, dt: float, box_size: float,
@@ -41,6 +43,7 @@ def rollout(model, data: Dict[str, torch.Tensor], metadata: dict, noise_std: flo
     tmp_traj = torch.empty((total_time, n, 1), dtype=torch.float32, device=device)
     pos_traj[:window_size] = coords[:window_size].to(device).float()
     tmp_traj[:window_size] = energy[:window_size].to(device).float()
+    consts = integration_constants(meta, device)
     with torch.no_grad():
         for t in range(window_size, total_time):
             win_p = pos_traj[t - window_size:t]                      # [W, N, 3] views, no copies
@@ -49,7 +52,7 @@ def rollout(model, data: Dict[str, torch.Tensor], metadata: dict, noise_std: flo
                                num_neighbors=num_neighbors, box_size=box_size, dt=dt, device=device,
                                reference_rng=reference_rng, check_bounds=False)
             pred = model(graph)
-            new_p, new_t = integrate_one_step(pred["acceleration"], pred["temp_rate"], win_p, win_t, meta)
+            new_p, new_t = integrate_one_step(pred["acceleration"], pred["temp_rate"], win_p, win_t, meta, consts)
             pos_traj[t] = new_p
             tmp_traj[t] = new_t
     return {"Coordinates": pos_traj, "InternalEnergy": tmp_traj}

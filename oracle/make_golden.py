@@ -121,7 +121,7 @@ def run_harness() -> None:
     (one_step_test.py:26-124), ``momentum_conservation_loss`` (validation.py:5-16 = train.py:107-118) on a ragged
     three-graph batch, and ``rollout`` (render_rollout.py:26-90) -- run behind the h5py / Batch stand-ins of
     ``oracle/reference_shim.py``; the restatement must reproduce each before the fixture is written."""
-    ost, val, rr = reference_shim.load_drivers()
+    ost, val, rr, gmeta = reference_shim.load_drivers()
     gn, du = reference_shim.load()
     n, k, d, nh, steps, T = 256, 16, 32, 2, 2, 12
     meta = dict(HARNESS_META)
@@ -184,7 +184,21 @@ def run_harness() -> None:
     assert traj["Coordinates"].shape == (W2 + R, n, 3)
     assert torch.equal(want["Coordinates"], traj["Coordinates"]) and torch.equal(want["InternalEnergy"], traj["InternalEnergy"])
 
+    # ---- generate_metadata.generate_metadata (generate_metadata.py:6-48): the ten normalisation statistics ----------
+    import json
+    import tempfile
+    gen = torch.Generator().manual_seed(77)
+    vel = (torch.randn(T, n, 3, generator=gen) * 0.4 + 0.05).numpy()
+    hacc = (torch.randn(T, n, 3, generator=gen) * 2.0 - 0.3).numpy()
+    reference_shim.register_h5("mem://harness_meta.hdf5", {
+        "Velocities": vel, "HydroAcceleration": hacc, "Coordinates": coords.numpy(), "InternalEnergy": energy.numpy(),
+        "BoxSize": np.asarray(meta["box_size"]), "TimeStep": np.asarray(meta["dt"])})
+    with tempfile.TemporaryDirectory() as tmp:
+        gmeta.generate_metadata("mem://harness_meta.hdf5", os.path.join(tmp, "metadata.json"))
+        ref_meta = json.load(open(os.path.join(tmp, "metadata.json")))
+
     out = dict(n=n, k=k, latent=d, nh=nh, steps=steps, frames=T, coords=coords.numpy(), energy=energy.numpy(),
+               velocities=vel, hydro_acceleration=hacc,
                one_step_window=W1, one_step_tested=np.asarray(res["tested_timesteps"], dtype=np.int64),
                one_step_position_errors=np.asarray(res["position_errors"], dtype=np.float64),
                one_step_temperature_errors=np.asarray(res["temperature_errors"], dtype=np.float64),
@@ -199,6 +213,8 @@ def run_harness() -> None:
         out[f"batch_energy{i}"] = e_.numpy()
     for key, v in meta.items():
         out["meta:" + key] = np.float64(v)
+    for key, v in ref_meta.items():
+        out["genmeta:" + key] = np.asarray(v, dtype=np.float64)
     for k_, v in sd1.items():
         out["w1:" + k_] = v.numpy()
     for k_, v in sd2.items():

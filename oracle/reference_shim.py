@@ -186,14 +186,14 @@ def load():
 
 
 def load_drivers():
-    """Returns ``(one_step_test, validation, render_rollout)`` = the reference's driver modules, importing the
+    """Returns ``(one_step_test, validation, render_rollout, generate_metadata)`` = the reference's driver modules, importing the
     reference's own ``graph_network`` / ``data_utils`` underneath (behind the stand-ins above)."""
     if not available():
         raise FileNotFoundError(f"reference checkout not found at {REFERENCE_DIR}")
     _install_standins()
     sys.dont_write_bytecode = True
     os.environ.setdefault("MPLBACKEND", "Agg")     # render_rollout.py imports matplotlib.pyplot at module level
-    names = ("graph_network", "data_utils", "one_step_test", "validation", "render_rollout")
+    names = ("graph_network", "data_utils", "one_step_test", "validation", "render_rollout", "generate_metadata")
     saved = {n: sys.modules.pop(n, None) for n in names}
     sys.path.insert(0, REFERENCE_DIR)
     try:
@@ -204,4 +204,4 @@ def load_drivers():
             sys.modules.pop(n, None)
             if saved[n] is not None:
                 sys.modules[n] = saved[n]
-    return mods[2], mods[3], mods[4]
+    return mods[2], mods[3], mods[4], mods[5]

@@ -8,6 +8,9 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cosmology_gnn_simulation_amd import _lib  # noqa: E402
+if os.environ.get("CGNN_LIB_PATH"):      # developer A/B: time another build of the library (scripts/ab/)
+    _lib.LIB_PATH = os.environ["CGNN_LIB_PATH"]
 from cosmology_gnn_simulation_amd import data_utils, graph_network, ops, synthetic  # noqa: E402
 
 ap = argparse.ArgumentParser()

@@ -41,7 +41,8 @@ def load_harness():
     """tests/golden/harness.npz: outputs of the reference's own driver functions (validate_one_step,
     momentum_conservation_loss on a ragged batch, rollout), see oracle/make_golden.py::run_harness."""
     z = np.load(os.path.join(GOLDEN_DIR, "harness.npz"))
-    g = {k: z[k] for k in z.files if not k.startswith(("w1:", "w2:", "meta:"))}
+    g = {k: z[k] for k in z.files if not k.startswith(("w1:", "w2:", "meta:", "genmeta:"))}
+    g["generated_metadata"] = {k[8:]: z[k] for k in z.files if k.startswith("genmeta:")}
     g["state_dict_one_step"] = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w1:")}
     g["state_dict_rollout"] = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w2:")}
     g["metadata"] = {k[5:]: float(z[k]) for k in z.files if k.startswith("meta:")}

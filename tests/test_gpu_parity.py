@@ -457,6 +457,16 @@ def test_on_device_rollout_vs_reference_driver(harness):
     # the reference builds rollout graphs WITHOUT noise whatever noise_std says (render_rollout.py:44-52)
     noisy = ro.rollout(m, data, meta, 0.1, meta["dt"], meta["box_size"], window_size=Wr)
     assert torch.equal(noisy["Coordinates"], got["Coordinates"]) and torch.equal(noisy["InternalEnergy"], got["InternalEnergy"])
+    # no host round trip inside a step.  With the inputs on the device and the weights packed (the calls
+    # above), a whole rollout must run without a single device synchronisation.
+    dev_data = {k_: v.to(DEV) for k_, v in data.items()}
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        again = ro.rollout(m, dev_data, meta, 0.0, meta["dt"], meta["box_size"], window_size=Wr)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert torch.equal(again["Coordinates"], got["Coordinates"])
 
 
 def test_random_init_matches_reference_rng_order():
@@ -655,3 +665,40 @@ def test_hip_graph_replay_equals_eager(golden_tiny):
         eager2 = m(d2)
     out2 = gf(x2)
     assert torch.equal(out2["acceleration"], eager2["acceleration"])
+
+
+def test_fixed_k_hint_is_bound_to_its_edge_index(golden_tiny):
+    """A caller that reorders the edges of a preprocessed graph (same size, no longer receiver-sorted) must get the
+    general path, not the fixed-k kernels on a stale hint: results equal the oracle on the reordered list."""
+    g = golden_tiny
+    c, e = torch.from_numpy(g["coords"]), torch.from_numpy(g["energy"])
+    d = data_utils.preprocess(c[:W].clone(), e[:W].clone(), g["metadata"], None, None, 0.0, int(g["k"]), g["metadata"]["dt"],
+                              g["metadata"]["box_size"])
+    m = _model(g)
+    with torch.no_grad():
+        want = m(d)
+    perm = torch.randperm(d.edge_index.shape[1], generator=torch.Generator().manual_seed(0)).to(DEV)
+    d.edge_index = d.edge_index[:, perm].contiguous()        # same shape, shuffled order; the hint object is still there
+    d.edge_attr = d.edge_attr[perm].contiguous()
+    assert getattr(d, "_cgnn_fixed_k", None) == int(g["k"])
+    with torch.no_grad():
+        got = m(d)
+    assert rel_err(got["acceleration"], want["acceleration"]) <= TOL      # sums in another order, same values
+    src, dst, fk = graph_network._graph_arrays(d, d.x.shape[0])
+    assert fk == 0
+
+
+def test_invalidate_packed_after_a_data_update(golden_tiny):
+    g = golden_tiny
+    m = _model(g)
+    with torch.no_grad():
+        a = m(_graph(g))
+        for p_ in m.parameters():
+            p_.data.mul_(0.5)                    # does not bump the parameter's version counter
+        m.invalidate_packed()
+        b = m(_graph(g))
+    sd = {k_: v * 0.5 for k_, v in g["state_dict"].items()}
+    want = cpu_ref.encode_process_decode(sd, torch.from_numpy(g["x"]), edge_index_from(g), torch.from_numpy(g["edge_attr"]),
+                                         int(g["nh"]), int(g["steps"]))
+    assert rel_err(b["acceleration"].cpu(), want["acceleration"]) <= TOL
+    assert not torch.equal(a["acceleration"], b["acceleration"])

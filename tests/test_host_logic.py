@@ -128,3 +128,23 @@ def test_reference_module_names_resolve_to_the_engine(tmp_path):
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(root, "compat"), os.path.join(root, "compat", "pyg_free")])
     out = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), env=env, capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+def test_generate_metadata_matches_reference_driver():
+    """The ten statistics against the reference's own generate_metadata.generate_metadata (generate_metadata.py:6-48),
+    run behind the h5py stand-in by oracle/make_golden.py (tests/golden/harness.npz): same keys, same list-vs-scalar
+    shapes, same values (the reference reduces in float32, this restatement in float64)."""
+    import numpy as np
+    from conftest import load_harness
+    from cosmology_gnn_simulation_amd import snapshot_io
+    h = load_harness()
+    snap = {"Coordinates": torch.from_numpy(h["coords"]), "InternalEnergy": torch.from_numpy(h["energy"]),
+            "Velocities": torch.from_numpy(h["velocities"]), "HydroAcceleration": torch.from_numpy(h["hydro_acceleration"]),
+            "BoxSize": torch.tensor(h["metadata"]["box_size"]), "TimeStep": torch.tensor(h["metadata"]["dt"])}
+    got = snapshot_io.generate_metadata(snap)
+    want = h["generated_metadata"]
+    assert sorted(got) == sorted(want)
+    for key, w in want.items():
+        g = np.asarray(got[key], dtype=np.float64)
+        assert g.shape == w.shape, key                       # temperature statistics are length-1 lists, the rest scalars
+        assert np.allclose(g, w, rtol=1e-5, atol=1e-7), (key, g, w)
