@@ -85,26 +85,73 @@ class Shard:
         return self.n_owned + self.n_ghost
 
 
+def tile_bounds(box_size: float, world: int, rank: int):
+    """``(lo [3], hi [3])`` of rank ``rank``'s tile (the inverse of :func:`owner_of`)."""
+    px, py, pz = tile_grid(world)
+    ix, iy, iz = rank // (py * pz), (rank // pz) % py, rank % pz
+    lo = [ix * box_size / px, iy * box_size / py, iz * box_size / pz]
+    hi = [(ix + 1) * box_size / px, (iy + 1) * box_size / py, (iz + 1) * box_size / pz]
+    return lo, hi
+
+
+def _near_tile(pos: torch.Tensor, box_size: float, lo, hi, margin: float) -> torch.Tensor:
+    """Particles within ``margin`` of the tile [lo, hi) along every axis, periodic (a superset of the margin ball)."""
+    keep = torch.ones(pos.shape[0], dtype=torch.bool, device=pos.device)
+    for a in range(3):
+        width = hi[a] - lo[a]
+        if width + 2 * margin >= box_size:
+            continue                                  # the expanded tile covers this axis
+        c = 0.5 * (lo[a] + hi[a])
+        d = torch.abs(pos[:, a] - c)
+        d = torch.minimum(d, box_size - d)            # periodic distance to the tile centre
+        keep &= d <= 0.5 * width + margin
+    return keep
+
+
 def build_shard(pos_global: torch.Tensor, box_size: float, k: int, world: int, rank: int,
-                knn_fn: Optional[Callable] = None) -> Shard:
+                knn_fn: Optional[Callable] = None, margin_factor: float = 2.0) -> Shard:
     """Everything rank ``rank`` can derive locally from the global positions: its owned set, their k-NN
     senders, the ghost set and the global->local renumbering.  ``knn_fn(pos, box, k, query_ids)`` defaults to
-    the HIP k-NN; it returns ``(senders int32 [nq*k], edge_attr [nq*k, 4], order)``."""
+    the HIP k-NN; it returns ``(senders int32 [nq*k], edge_attr [nq*k, 4], order)``.
+
+    The neighbour search runs over the rank's tile plus a margin, not over the whole box ("graph
+    build"): margin = ``margin_factor`` x the radius that holds k particles at mean density.  It is then CHECKED --
+    every owned particle's k-th neighbour must be closer than the margin, or some neighbour outside the subset could
+    have been missed -- and doubled until the check holds (clustered inputs), so the result is the global one."""
     dev = pos_global.device
     n_total = pos_global.shape[0]
     owner = owner_of(pos_global, box_size, world)
-    owned = torch.nonzero(owner == rank).squeeze(1)
     knn = knn_fn or (lambda p, b, kk, q: ops.knn_periodic(p, b, kk, query_ids=q, want_edge_attr=True,
                                                           want_order=True))
     t0 = time.perf_counter()
-    # a one-query pass builds the cell grid and yields the spatial (cell-sorted) order, so that the local
-    # numbering is cache friendly; then the real pass over the owned queries in that order
-    if owned.numel():
-        _, _, order = knn(pos_global, box_size, k, owned[:1].to(torch.int32))
-        if order is not None:
-            order = order.long()
-            owned = order[owner[order] == rank]
-    senders, edge_attr, _ = knn(pos_global, box_size, k, owned.to(torch.int32))
+    lo, hi = tile_bounds(box_size, world, rank)
+    margin = margin_factor * box_size * (3.0 * k / (4.0 * 3.141592653589793 * max(n_total, 1))) ** (1.0 / 3.0)
+    while True:
+        near = _near_tile(pos_global, box_size, lo, hi, margin) if world > 1 else None
+        whole = near is None or bool(near.all())
+        sub = None if whole else torch.nonzero(near).squeeze(1)        # ascending global ids: ties order as globally
+        pos_sub = pos_global if whole else pos_global[sub].contiguous()
+        own_sub = owner if whole else owner[sub]
+        owned_s = torch.nonzero(own_sub == rank).squeeze(1)            # indices into the subset
+        # a one-query pass builds the cell grid and yields the spatial (cell-sorted) order, so that the local
+        # numbering is cache friendly; then the real pass over the owned queries in that order
+        if owned_s.numel():
+            _, _, order = knn(pos_sub, box_size, k, owned_s[:1].to(torch.int32))
+            if order is not None:
+                order = order.long()
+                owned_s = order[own_sub[order] == rank]
+        senders_s, edge_attr, _ = knn(pos_sub, box_size, k, owned_s.to(torch.int32))
+        if whole or owned_s.numel() == 0:
+            break
+        # k-th neighbour distance (minimum image) of every owned particle against the margin
+        kth = senders_s.view(-1, k)[:, k - 1].long()
+        dlt = torch.abs(pos_sub[kth] - pos_sub[owned_s])
+        dlt = torch.minimum(dlt, box_size - dlt)
+        if float(dlt.norm(dim=1).max()) <= margin:
+            break
+        margin *= 2.0
+    owned = owned_s if whole else sub[owned_s]
+    senders = senders_s.long() if whole else sub[senders_s.long()]
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
     knn_ms = (time.perf_counter() - t0) * 1e3

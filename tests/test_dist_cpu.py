@@ -96,3 +96,66 @@ def test_single_process_plan_consistency():
         got_owner = own[sh.ghost_global].tolist()
         assert got_owner == sorted(got_owner)
         assert torch.equal(sh.owned_global[sh.send_idx.long()], torch.cat([shards[p].want_global[r] for p in range(4)]))
+
+
+def _global_senders(pos, k):
+    ei, _ = cpu_ref.knn_periodic(pos, BOX, k)
+    return ei[0].view(pos.shape[0], k)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_tile_plus_margin_search_equals_the_global_search(world):
+    """build_shard searches its tile plus a margin, checks every k-th neighbour against the margin and widens it until
+    the check holds: the senders must be the global k-NN's, also when the particles are clustered and the first margin
+    (mean-density estimate) is far too small."""
+    gen = torch.Generator().manual_seed(5)
+    uniform = torch.rand(900, 3, generator=gen) * BOX
+    # nine tight clusters + a thin uniform background: most k-th neighbours of background particles are far away
+    centres = torch.rand(9, 3, generator=gen) * BOX
+    clustered = torch.cat([torch.remainder(centres[i] + 0.01 * torch.randn(90, 3, generator=gen), BOX) for i in range(9)] +
+                          [torch.rand(90, 3, generator=gen) * BOX])
+    for pos in (uniform, clustered):
+        want = _global_senders(pos, K)
+        calls = []
+
+        def knn(p, b, kk, q):
+            calls.append(p.shape[0])
+            return _oracle_knn(p, b, kk, q)
+        seen = 0
+        for r in range(world):
+            sh = cdist.build_shard(pos, BOX, K, world, r, knn_fn=knn)
+            local_to_global = torch.cat([sh.owned_global, sh.ghost_global])
+            got = local_to_global[sh.src_local.long()].view(sh.n_owned, K)
+            assert torch.equal(got, want[sh.owned_global]), (world, r)
+            seen += sh.n_owned
+        assert seen == pos.shape[0]
+
+
+def test_tile_plus_margin_search_runs_over_a_subset_of_the_box():
+    """At a density where tile + 2 x margin is narrower than the box the per-rank search sees a fraction of the
+    particles (and still returns the global neighbours)."""
+    gen = torch.Generator().manual_seed(6)
+    pos = torch.rand(20000, 3, generator=gen) * BOX
+    want = _global_senders(pos, K)
+    calls = []
+
+    def knn(p, b, kk, q):
+        calls.append(p.shape[0])
+        return _oracle_knn(p, b, kk, q)
+    for r in (0, 5):
+        sh = cdist.build_shard(pos, BOX, K, 8, r, knn_fn=knn)
+        local_to_global = torch.cat([sh.owned_global, sh.ghost_global])
+        assert torch.equal(local_to_global[sh.src_local.long()].view(sh.n_owned, K), want[sh.owned_global])
+    assert max(calls) < pos.shape[0] // 2, calls
+
+
+def test_tile_bounds_invert_owner_of():
+    pos = _positions()
+    for world in (2, 4, 8):
+        own = cdist.owner_of(pos, BOX, world)
+        for r in range(world):
+            lo, hi = cdist.tile_bounds(BOX, world, r)
+            inside = torch.ones(N, dtype=torch.bool)
+            for a in range(3):
+                inside &= (pos[:, a] >= lo[a]) & (pos[:, a] < hi[a])
+            assert torch.equal(inside, own == r)
