@@ -55,8 +55,9 @@ def parse_args():
     p.add_argument("--mp-steps", type=int, default=None)
     p.add_argument("--hidden-layers", type=int, default=2)
     p.add_argument("--edge-precision", default=None, choices=["bf16", "fp32"])
-    p.add_argument("--node-precision", default=None, choices=["bf16", "fp32", "fp32x3"],
-                   help="fp32x3 = f32 emulated with three bf16 terms on the bf16 matrix cores (holds the 1e-5 gate)")
+    p.add_argument("--node-precision", default=None, choices=["bf16", "fp32", "fp32x3", "fp16x2"],
+                   help="f32 emulated on the matrix cores, both hold the 1e-5 gate: fp32x3 = three bf16 terms, six products; "
+                        "fp16x2 = two fp16 terms, three products (half the matrix work; |activation| < 65504)")
     p.add_argument("--message-source", default="x_j", choices=["x_j", "edge"])
     p.add_argument("--no-fuse-rounds", action="store_true",
                    help="x_j mode: one edge-kernel launch per round instead of cgnn_edge_stream (all rounds in one launch)")
@@ -73,9 +74,9 @@ def parse_args():
     a = p.parse_args()
     # BASELINE.json configs[0..4] (N, k, latent, rounds, edge / node arithmetic, seed 1234 + cfg)
     presets = {"cfg1": (4096, 8, 64, 5, "fp32", "fp32", 1235, "weak"), "cfg2": (262144, 16, 128, 10, "fp32", "fp32", 1236, "weak"),
-               "cfg3": (1_000_000, 16, 128, 10, "bf16", "fp32x3", 1236, "weak"),
-               "cfg4": (4_000_000, 16, 128, 10, "bf16", "fp32x3", 1238, "strong"),
-               "cfg5": (1_000_000, 32, 256, 15, "bf16", "fp32x3", 1239, "strong")}
+               "cfg3": (1_000_000, 16, 128, 10, "bf16", "fp16x2", 1236, "weak"),
+               "cfg4": (4_000_000, 16, 128, 10, "bf16", "fp16x2", 1238, "strong"),
+               "cfg5": (1_000_000, 32, 256, 15, "bf16", "fp16x2", 1239, "strong")}
     pre = presets[a.config or "cfg3"]
     for name, val in zip(("particles", "neighbors", "latent", "mp_steps", "edge_precision", "node_precision", "seed"), pre):
         if getattr(a, name) is None:

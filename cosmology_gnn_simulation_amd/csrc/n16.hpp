@@ -424,6 +424,147 @@ __device__ __forceinline__ void dense16x3_part(f32x4 (&out)[OT], const bf16x8 (&
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// CGNN_F16X2 arithmetic in the N16 layout: f32 emulated with TWO fp16 terms per value and three MFMAs per fragment
+// (v_mfma_f32_16x16x32_f16), half the matrix work of the three-bf16-term form for the same accuracy.
+//
+//   x = hi + lo / 2048,   hi = fp16(x),   lo = fp16((x - hi) * 2048)
+//
+// hi keeps 11 significand bits, the residual x - hi is exact in f32 and has at most 13 more, of which lo keeps 11:
+// |x - (hi + lo/2048)| <= 2^-23 |x|.  The residual is scaled by 2^11 before the conversion so that it stays a normal
+// fp16 number wherever hi is one (unscaled it would sink into fp16's subnormals for |x| < 2^-3 and lose bits); the
+// products that carry one scaled term go to a second accumulator that is folded in with weight 2^-11:
+//
+//   sum x w = sum hi_x hi_w  +  2^-11 (sum hi_x lo_w + sum lo_x hi_w)  +  O(2^-22 |x| |w|)   [lo_x lo_w dropped]
+//
+// fp16 products are exact in the f32 accumulator, fp16 subnormal operands are honoured by the instruction (probe:
+// scripts/dev/probe_f16_mfma.hip), so tiny values only lose the bits below 2^-35.  The one thing fp16 cannot hold is
+// |x| >= 65520: hi becomes inf and the row's results are inf/NaN (visible, never silently wrong).  Latents behind a
+// LayerNorm and sums of <= 64 of them are orders of magnitude below that; CGNN_F32X3 has the f32 range.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+struct f16x8x2 {
+    f16x8 p[2];
+};
+#define CGNN_F16X2_SCALE 2048.0f
+#define CGNN_F16X2_INV_SCALE (1.0f / 2048.0f)
+
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_));
+}
+
+// two values -> (hi pair, lo pair)
+__device__ __forceinline__ void split_f16x2(float a, float b, unsigned& hi, unsigned& lo) {
+    typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+    hi = pack_f16(a, b);
+    const f16x2_ h = __builtin_bit_cast(f16x2_, hi);
+    lo = pack_f16((a - (float)h[0]) * CGNN_F16X2_SCALE, (b - (float)h[1]) * CGNN_F16X2_SCALE);
+}
+
+template <bool RELU, int KS>
+__device__ __forceinline__ void operand16f2(f16x8 (&op)[2][KS], const f32x4 (&acc)[2 * KS]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        u32x4 hi, lo;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float a = acc[2 * s + (t >> 1)][2 * (t & 1)], b = acc[2 * s + (t >> 1)][2 * (t & 1) + 1];
+            if (RELU) {     // NaN stays NaN (fmaxf would turn it into 0 and hide an fp16 overflow, see above)
+                a = a < 0.f ? 0.f : a;
+                b = b < 0.f ? 0.f : b;
+            }
+            unsigned h, l;
+            split_f16x2(a, b, h, l);
+            hi[t] = h;
+            lo[t] = l;
+        }
+        op[0][s] = __builtin_bit_cast(f16x8, hi);
+        op[1][s] = __builtin_bit_cast(f16x8, lo);
+    }
+}
+
+// the two accumulators of a layer folded into its value: c0 + c1 / 2048
+template <int OT>
+__device__ __forceinline__ void fold16f2(f32x4 (&c0)[OT], const f32x4 (&c1)[OT]) {
+#pragma unroll
+    for (int o = 0; o < OT; ++o) c0[o] += c1[o] * CGNN_F16X2_INV_SCALE;
+}
+
+// Two-part (CGNN_F16X2_N16) fragments in LDS: [m][part][lane][8 fp16]
+struct LdsWf2 {
+    LdsWeightPtr p;
+    __device__ __forceinline__ explicit LdsWf2(LdsWeightPtr q) : p(q) {}
+    __device__ __forceinline__ f16x8x2 fetch(int m, int lane) const {
+        f16x8x2 r;
+        r.p[0] = __builtin_bit_cast(f16x8, p[(m * 2) * 64 + lane]);
+        r.p[1] = __builtin_bit_cast(f16x8, p[(m * 2 + 1) * 64 + lane]);
+        return r;
+    }
+};
+
+// fragments [M0, M1) of a layer (m = O * KS + s) from an LDS chunk holding exactly that range: c0 takes hi.hi, c1 the
+// two cross products.  Groups of two fragments (same output tile, consecutive k-steps); c0 and c1 alternate.
+template <int KS, int OT, int M0, int M1>
+__device__ __forceinline__ void dense16f2_part(f32x4 (&c0)[OT], f32x4 (&c1)[OT], const f16x8 (&in)[2][KS],
+                                               const LdsWf2& wp, int lane) {
+    constexpr int M = M1 - M0;
+    constexpr int GS = (M < 2) ? M : 2;
+    constexpr int NG = M / GS;
+    static_assert(M % GS == 0 && M1 <= OT * KS, "bad fragment range");
+    f16x8x2 buf[2][GS];
+#pragma unroll
+    for (int j = 0; j < GS; ++j) buf[0][j] = wp.fetch(j, lane);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int j = 0; j < GS; ++j) buf[(g + 1) & 1][j] = wp.fetch((g + 1) * GS + j, lane);
+        }
+#pragma unroll
+        for (int j = 0; j < GS; ++j) {
+            const int mm = M0 + g * GS + j;
+            const int o = mm / KS, s = mm % KS;
+            const f16x8x2& a = buf[g & 1][j];
+            c0[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.p[0], in[0][s], c0[o], 0, 0, 0);
+            c1[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.p[0], in[1][s], c1[o], 0, 0, 0);
+            c1[o] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.p[1], in[0][s], c1[o], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// The same arithmetic for the five-slot-ring node kernel (node_block_f2.hip): a ring chunk holds the 8 fragments of
+// output tiles O0, O0 + 1 over the four k-steps ([tile][k-step][part][lane]); a GROUP is the two tiles at one k-step,
+// six MFMAs on four different accumulators (a dependent pair is two instructions apart).  The fragment reads are inline
+// asm with counted lgkmcnt waits and run two groups ahead of the MFMAs -- across chunk boundaries too (the kernel's
+// barrier for chunk q also vouches for chunk q + 1), so only the first group of a step waits for a whole LDS round trip.
+struct FragPipe16f2 {
+    u32x4 buf[3][4];     // [group % 3][hi(O0), lo(O0), hi(O0+1), lo(O0+1)]
+    // request group g (k-step) of the chunk at LDS byte address addr (+ lane * 16 already added)
+    template <int SLOT, int G>
+    __device__ __forceinline__ void request(unsigned addr) {
+        buf[SLOT][0] = lds_read_b128<(0 * 4 + G) * 2048>(addr);
+        buf[SLOT][1] = lds_read_b128<(0 * 4 + G) * 2048 + 1024>(addr);
+        buf[SLOT][2] = lds_read_b128<(1 * 4 + G) * 2048>(addr);
+        buf[SLOT][3] = lds_read_b128<(1 * 4 + G) * 2048 + 1024>(addr);
+    }
+    // group in SLOT is needed now; NEWER reads (of this pipe) were issued after it
+    template <int SLOT, int NEWER, int OT, int KS>
+    __device__ __forceinline__ void run(f32x4 (&c0)[OT], f32x4 (&c1)[OT], const f16x8 (&in)[2][KS], int o0, int s) {
+        lds_wait4<NEWER>(buf[SLOT][0], buf[SLOT][1], buf[SLOT][2], buf[SLOT][3]);
+        const f16x8 h0 = __builtin_bit_cast(f16x8, buf[SLOT][0]), l0 = __builtin_bit_cast(f16x8, buf[SLOT][1]);
+        const f16x8 h1 = __builtin_bit_cast(f16x8, buf[SLOT][2]), l1 = __builtin_bit_cast(f16x8, buf[SLOT][3]);
+        c0[o0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, in[0][s], c0[o0], 0, 0, 0);
+        c0[o0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, in[0][s], c0[o0 + 1], 0, 0, 0);
+        c1[o0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, in[1][s], c1[o0], 0, 0, 0);
+        c1[o0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, in[1][s], c1[o0 + 1], 0, 0, 0);
+        c1[o0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(l0, in[0][s], c1[o0], 0, 0, 0);
+        c1[o0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(l1, in[0][s], c1[o0 + 1], 0, 0, 0);
+    }
+};
+
 // bias / LayerNorm vectors straight from global memory (the node kernel's LDS is taken by the weight ring)
 template <int OT>
 __device__ __forceinline__ void fill16_global(f32x4 (&acc)[OT], const float* __restrict__ b, int q) {

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(CGNN_BLOCK) void node_block_x3_kernel(MlpDev m, X3C
 using namespace cgnn;
 
 namespace cgnn {
-int node_block_x3n16(const MlpDev& m, const cgnn_linear* w_x, const cgnn_linear* w_agg, const float* x,
+int node_block_x3n16(const MlpDev& m, int precision, const cgnn_linear* w_x, const cgnn_linear* w_agg, const float* x,
                      const float* agg, int64_t n, float* x_out, int residual, int T, bool fuse,
                      const cgnn_linear* ws_next, const cgnn_linear* wd_next, void* ps_next, void* pd_next, int p_format,
                      hipStream_t st);   // node_block_n16.hip
@@ -244,9 +244,9 @@ extern "C" int cgnn_node_block(const cgnn_mlp* mlp, const cgnn_linear* w_x, cons
     const float* b1 = w_x->b ? w_x->b : w_agg->b;
 
     // ---- 16-row F32X3 kernel (weights packed CGNN_F32X3_N16): two waves per SIMD ----
-    if (prec == CGNN_F32X3_N16) {
+    if (prec == CGNN_F32X3_N16 || prec == CGNN_F16X2_N16) {
         if (HT != DT || !(DT == 1 || DT == 2 || DT == 4)) {
-            set_error("cgnn_node_block: CGNN_F32X3_N16 needs hidden == latent in {32, 64, 128}");
+            set_error("cgnn_node_block: CGNN_F32X3_N16 / CGNN_F16X2_N16 need hidden == latent in {32, 64, 128}");
             return CGNN_ERR_UNSUPPORTED;
         }
         bool fuse = false;
@@ -260,7 +260,7 @@ extern "C" int cgnn_node_block(const cgnn_mlp* mlp, const cgnn_linear* w_x, cons
                 return CGNN_ERR_UNSUPPORTED;
             }
         }
-        rc = node_block_x3n16(m, w_x, w_agg, x, agg, n, x_out, residual, DT, fuse, ws_next, wd_next, ps_next, pd_next,
+        rc = node_block_x3n16(m, prec, w_x, w_agg, x, agg, n, x_out, residual, DT, fuse, ws_next, wd_next, ps_next, pd_next,
                               p_format, st);
         if (rc != CGNN_OK || fuse || !want_proj) return rc;
         return cgnn_project_nodes(ws_next, wd_next, proj_precision, x_out, n, ps_next, pd_next, p_format, stream);

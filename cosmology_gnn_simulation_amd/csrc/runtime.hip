@@ -144,6 +144,26 @@ __global__ void pack_f32x3_n16_kernel(const float* __restrict__ w, int out_dim, 
     wp[idx] = part == 0 ? w1 : (part == 1 ? w2 : w3);
 }
 
+// CGNN_F16X2_N16: the N16 fragment order with two fp16 terms per weight, [m][part][lane][j]: part 0 = fp16(w), part 1 =
+// fp16((w - part0) * 2048)  (n16.hpp, CGNN_F16X2 arithmetic).
+__global__ void pack_f16x2_n16_kernel(const float* __restrict__ w, int out_dim, int ld, int col0, int ncols, int KS,
+                                      int64_t total, _Float16* __restrict__ wp) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int j = (int)(idx & 7);
+    const int l = (int)((idx >> 3) & 63);
+    const int64_t mp = idx >> 9;
+    const int part = (int)(mp & 1);
+    const int64_t m = mp >> 1;
+    const int s = (int)(m % KS);
+    const int o = (int)(m / KS);
+    const int row = 16 * o + (l & 15);
+    const int k = 32 * s + 16 * (j >> 2) + 4 * (l >> 4) + (j & 3);
+    const float v = (row < out_dim && k < ncols) ? w[(int64_t)row * ld + col0 + k] : 0.f;
+    const _Float16 hi = (_Float16)v;
+    wp[idx] = part == 0 ? hi : (_Float16)((v - (float)hi) * 2048.0f);
+}
+
 // ------------------------------------------------------------------ aggregation
 // Fixed in-degree, receiver-sorted: one (row, 16-byte chunk) per thread; the k
 // neighbour rows are read with 16 B per lane, a row's chunks on adjacent lanes.
@@ -533,6 +553,7 @@ size_t cgnn_packed_linear_bytes(int32_t out_dim, int32_t ncols, int32_t precisio
     const size_t kt = (size_t)(ncols + 31) / 32;
     if (precision == CGNN_BF16_N16) return (size_t)((out_dim + 15) / 16) * kt * 1024;
     if (precision == CGNN_F32X3_N16) return (size_t)((out_dim + 15) / 16) * kt * 3072;
+    if (precision == CGNN_F16X2_N16) return (size_t)((out_dim + 15) / 16) * kt * 2048;
     const size_t ot = (size_t)(out_dim + 31) / 32;
     return ot * kt * 1024 * (precision == CGNN_BF16 ? 2 : (precision == CGNN_F32X3 ? 6 : 4));
 }
@@ -549,6 +570,12 @@ int cgnn_pack_linear(const float* w, int32_t out_dim, int32_t ld, int32_t col0, 
         const int64_t tot = (int64_t)((out_dim + 15) / 16) * KT * 512 * 3;
         pack_f32x3_n16_kernel<<<(unsigned)((tot + CGNN_BLOCK - 1) / CGNN_BLOCK), CGNN_BLOCK, 0, st>>>(
             w, out_dim, ld, col0, ncols, KT, tot, (__bf16*)packed);
+        return check_hip(hipGetLastError(), "cgnn_pack_linear launch");
+    }
+    if (precision == CGNN_F16X2_N16) {
+        const int64_t tot = (int64_t)((out_dim + 15) / 16) * KT * 512 * 2;
+        pack_f16x2_n16_kernel<<<(unsigned)((tot + CGNN_BLOCK - 1) / CGNN_BLOCK), CGNN_BLOCK, 0, st>>>(
+            w, out_dim, ld, col0, ncols, KT, tot, (_Float16*)packed);
         return check_hip(hipGetLastError(), "cgnn_pack_linear launch");
     }
     if (precision == CGNN_BF16_N16) {

@@ -347,7 +347,7 @@ class ShardedForward:
         if i + 1 < len(rounds):
             q = rounds[i + 1]
             if q.p_format == p.p_format and q.p_dtype == self.ps.dtype:
-                fused_ok = p.node.precision == _lib.F32X3_N16 and q.ws_fused.precision == _lib.BF16_N16
+                fused_ok = p.node.precision in _lib.N16_NODE and q.ws_fused.precision == _lib.BF16_N16
                 nxt = (q.ws_fused if fused_ok else q.ws, q.wd_fused if fused_ok else q.wd, ps_own, self.pd, q.p_format)
         ops.node_block(p.node, p.wx, p.wa, x_own, self.agg, x_own, True, nxt)
         self._projected = nxt is not None
@@ -372,7 +372,7 @@ class ShardedForward:
             nxt = None
             if i + 1 < len(rounds):
                 q = rounds[i + 1]
-                fused_ok = p.node.precision == _lib.F32X3_N16 and q.ws_fused.precision == _lib.BF16_N16
+                fused_ok = p.node.precision in _lib.N16_NODE and q.ws_fused.precision == _lib.BF16_N16
                 nxt = (q.ws_fused if fused_ok else q.ws, q.wd_fused if fused_ok else q.wd, self.ps[i + 1][a:b],
                        self.pd[i + 1][a:b], q.p_format)
             ops.node_block(p.node, p.wx, p.wa, x_in, self.agg[a:b], self.x_alt[a:b], True, nxt)

@@ -241,14 +241,15 @@ class _PackedProcessor:
         # cat([x, aggregated]) -> [Wx | Wa]                         (reference graph_network.py:94)
         node_fmt = node_precision
         if ops._prec(node_precision) == _lib.F32X3 and D <= 128 and w1n.shape[0] == D:
-            node_fmt = "fp32x3_n16"     # square layers <= 128: the 16-row, two-waves-per-SIMD node kernel
+            # square layers <= 128: the 16-row, two-waves-per-SIMD node kernel, on two fp16 or three bf16 terms
+            node_fmt = "fp16x2_n16" if str(node_precision).lower() in ("fp16x2", "f16x2") else "fp32x3_n16"
         self.wx = ops.PackedLinear(w1n, b1n, node_fmt, 0, D)
         self.wa = ops.PackedLinear(w1n, None, node_fmt, D, D)
         self.node = _pack_mlp(net.node_model, node_fmt, first_layer_cols=(0, D))
         # projection weights in the packing the PREVIOUS round's node kernel can fuse (it produces this round's
         # Ps / Pd): the N16 node kernel takes CGNN_BF16_N16, everything else the 32-row packing above
         self.ws_fused, self.wd_fused = self.ws, self.wd
-        if self.node.precision == _lib.F32X3_N16 and self.ws.precision == _lib.BF16 and w1e.shape[0] == D:
+        if self.node.precision in _lib.N16_NODE and self.ws.precision == _lib.BF16 and w1e.shape[0] == D:
             self.ws_fused = ops.PackedLinear(w1e, None, "bf16_n16", 0, D)
             self.wd_fused = ops.PackedLinear(w1e, b1e, "bf16_n16", D, D)
 
@@ -286,7 +287,7 @@ def _run_round(p: _PackedProcessor, x: torch.Tensor, e: torch.Tensor, src, dst, 
             agg = ops.aggregate(e_upd, None, dst, n, fixed_k, src.numel(), agg)
     nxt = None
     if next_round is not None and next_round.p_format == p.p_format and next_round.p_dtype == ps.dtype:
-        fused_ok = p.node.precision == _lib.F32X3_N16 and next_round.ws_fused.precision == _lib.BF16_N16
+        fused_ok = p.node.precision in _lib.N16_NODE and next_round.ws_fused.precision == _lib.BF16_N16
         nxt = (next_round.ws_fused if fused_ok else next_round.ws, next_round.wd_fused if fused_ok else next_round.wd,
                ps, pd, next_round.p_format)
     x_new = ops.node_block(p.node, p.wx, p.wa, x, agg, x_out, residual, nxt)
@@ -310,7 +311,7 @@ def _run_rounds_fused(rounds, x: torch.Tensor, e, src, dst, fixed_k: int, agg: O
         nxt = None
         if i + 1 < L:
             q = rounds[i + 1]
-            fused_ok = p.node.precision == _lib.F32X3_N16 and q.ws_fused.precision == _lib.BF16_N16
+            fused_ok = p.node.precision in _lib.N16_NODE and q.ws_fused.precision == _lib.BF16_N16
             nxt = (q.ws_fused if fused_ok else q.ws, q.wd_fused if fused_ok else q.wd, ps_all[i + 1], pd_all[i + 1], fmt)
         x = ops.node_block(p.node, p.wx, p.wa, x, agg, x, True, nxt)
     # `encoder` (the packed edge encoder) given: the initial edge latents are computed inside the same launch and

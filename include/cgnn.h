@@ -52,9 +52,18 @@ typedef enum {
                           >= 2^-16 accumulated in f32 (a1b1,a1b2,a2b1,a2b2,a1b3,a3b1); dropped
                           terms are <= 2^-24 relative.  2.7x the f32-MFMA rate at f32-level
                           error; cgnn_mlp_rows and cgnn_node_block                          */
-    CGNN_F32X3_N16 = 4 /* CGNN_F32X3 arithmetic, weights packed for the 16-row-per-wave node kernel
+    CGNN_F32X3_N16 = 4, /* CGNN_F32X3 arithmetic, weights packed for the 16-row-per-wave node kernel
                           (v_mfma_f32_16x16x32_bf16, two waves per SIMD); cgnn_node_block only,
                           square layers, its projection epilogue takes CGNN_BF16_N16 weights    */
+    CGNN_F16X2_N16 = 5  /* f32 emulated on the fp16 matrix cores (v_mfma_f32_16x16x32_f16): operands split
+                          into two fp16 terms, x = hi + lo/2048 with lo = fp16((x - hi) * 2048) (11 + 11
+                          significand bits, the residual scaled so it stays a normal fp16 number); three
+                          products per element (hi.hi, hi.lo, lo.hi; lo.lo <= 2^-22 relative dropped), the
+                          scaled ones summed in a second f32 accumulator.  Half the matrix work of
+                          CGNN_F32X3 at the same error.  Range: |activation| < 65520 (fp16), beyond it the
+                          row turns into inf/NaN (never a silently wrong number); use CGNN_F32X3 for
+                          unnormalised inputs.  16-row packing; cgnn_node_block (square layers <= 128,
+                          projection epilogue CGNN_BF16_N16) and cgnn_edge_block                  */
 } cgnn_precision;
 
 /* Element type / row order of the Ps, Pd gather tables (cgnn_project_nodes -> cgnn_edge_block).

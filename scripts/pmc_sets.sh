@@ -11,7 +11,7 @@ i=0
 for SET in "$@"; do
   i=$((i+1))
   echo "pass $i: $SET"
-  timeout -k 5 240 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/p$i -- python3 $REPO/scripts/run_one_op.py $OP --node-precision fp32x3 $CGNN_RUN_ARGS > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+  timeout -k 5 240 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/p$i -- python3 $REPO/scripts/run_one_op.py $OP $CGNN_RUN_ARGS > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done
 python3 - <<PY
 import csv, glob, collections

@@ -13,7 +13,7 @@ if os.environ.get("CGNN_LIB_PATH"):      # developer A/B: time another build of 
 from cosmology_gnn_simulation_amd import data_utils, graph_network, ops, synthetic  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("op", choices=["edge_block", "edge_stream", "aggregate", "node_block", "project_nodes", "enc_edge", "knn"])
+ap.add_argument("op", choices=["edge_block", "edge_stream", "aggregate", "node_block", "node_block_proj", "project_nodes", "enc_edge", "knn"])
 ap.add_argument("--particles", type=int, default=1_000_000)
 ap.add_argument("--neighbors", type=int, default=16)
 ap.add_argument("--latent", type=int, default=128)
@@ -63,7 +63,16 @@ if a.op == "edge_stream":
     encL = None if imageL is not None else (PL["enc_edge"] if mL._encoder_fits_stream(PL) else None)
     ps_all = torch.randn(L, n, d, device=dev, generator=gen).to(torch.bfloat16)
     pd_all = torch.randn(L, n, d, device=dev, generator=gen).to(torch.bfloat16)
+if a.op == "node_block_proj":     # the node block as the fused forward runs it: next round's projections inside
+    m2 = graph_network.EncodeProcessDecode(d, d, 2, 2, 3)
+    m2.load_state_dict(synthetic.make_state_dict(d, d, 2, 2, 3))
+    m2 = m2.to(dev).eval()
+    m2.edge_precision, m2.node_precision = a.edge_precision, a.node_precision
+    r0, r1 = m2._pack(17, 4)["rounds"]
+    ps2, pd2 = ops.project_nodes(r1.ws, r1.wd, x, None, None, r1.p_format)
 fn = {
+    "node_block_proj": lambda: ops.node_block(r0.node, r0.wx, r0.wa, x, agg, x, True,
+                                              (r1.ws_fused, r1.wd_fused, ps2, pd2, r1.p_format)),
     "edge_stream": lambda: (ops.edge_stream_run(imageL, ps_all, pd_all, src, dst, None if imageL.enc_in else e, e,
                                                 ea if imageL.enc_in else None) if imageL is not None else
                             ops.edge_stream(roundsL, ps_all, pd_all, src, dst, None if encL else e, e, encL,

@@ -106,7 +106,7 @@ if not a.only or a.only == "aggregate_atomic":
     print(f"   (shuffled: {E * d * 4 / 1e9:.2f} GB of float atomics per call)")
     a.only = _o
 t("node_block", lambda: ops.node_block(p.node, p.wx, p.wa, x, agg, x, True), 3 * n * d * 4, 8.0 * n * d * d)
-if len(roundsL) > 1 and roundsL[0].node.precision == 4:      # F32X3_N16: projections of the next round fused in
+if len(roundsL) > 1 and roundsL[0].node.precision in _lib.N16_NODE:      # 16-row node kernels: projections of the next round fused in
     q_ = roundsL[1]
     t("node_block+proj", lambda: ops.node_block(roundsL[0].node, roundsL[0].wx, roundsL[0].wa, x, agg, x, True,
                                                 (q_.ws_fused, q_.wd_fused, ps, pd, q_.p_format)),

@@ -1,0 +1,134 @@
+"""GPU: cgnn_node_block in its two f32-emulating forms -- three bf16 terms (CGNN_F32X3_N16) and two fp16 terms
+(CGNN_F16X2_N16) -- against a float64 evaluation of the reference's node update (graph_network.py:94-96: node MLP on
+cat([x, aggregated]) with LayerNorm, :182 residual) and against the exact-f32 kernel.  Both must sit at f32 rounding
+level (the model-level 1e-5 gate is tested in test_gpu_parity.py); the fused projection epilogue carries the bf16
+table's own rounding."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cosmology_gnn_simulation_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand_node_mlp(gen, d, nh, w_scale=1.0):
+    dims = [2 * d] + [d] * nh + [d]
+    lin = []
+    for i in range(nh + 1):
+        bound = w_scale / np.sqrt(dims[i])
+        w = (torch.rand(dims[i + 1], dims[i], generator=gen) * 2 - 1) * bound
+        b = (torch.rand(dims[i + 1], generator=gen) * 2 - 1) * bound
+        lin.append((w.to(DEV), b.to(DEV)))
+    ln = ((1 + 0.1 * torch.randn(d, generator=gen)).to(DEV), (0.1 * torch.randn(d, generator=gen)).to(DEV))
+    return lin, ln
+
+
+def _f64(lin, ln, x, agg, residual=True):
+    h = torch.cat([x, agg], dim=1).double()
+    for i, (w, b) in enumerate(lin):
+        h = h @ w.double().t() + b.double()
+        if i < len(lin) - 1:
+            h = torch.relu(h)
+    h = F.layer_norm(h, (h.shape[1],), ln[0].double(), ln[1].double(), 1e-5)
+    return h + x.double() if residual else h
+
+
+def _run(fmt, lin, ln, x, agg, residual=True):
+    d = x.shape[1]
+    w1, b1 = lin[0]
+    wx = ops.PackedLinear(w1, b1, fmt, 0, d)
+    wa = ops.PackedLinear(w1, None, fmt, d, d)
+    mlp = ops.PackedMLP([(w1[:, :d].contiguous(), None)] + lin[1:], ln, fmt)
+    out = ops.node_block(mlp, wx, wa, x, agg, None, residual)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("fmt", ["fp32x3_n16", "fp16x2_n16"])
+@pytest.mark.parametrize("n,d,nh", [(1000, 128, 2), (17, 128, 2), (4099, 64, 1), (300, 32, 3), (70000, 128, 2)])
+def test_node_block_f32_emulations_sit_at_f32_rounding_level(fmt, n, d, nh):
+    gen = torch.Generator().manual_seed(n + d)
+    lin, ln = _rand_node_mlp(gen, d, nh)
+    x = torch.randn(n, d, generator=gen).to(DEV) * 2
+    agg = torch.randn(n, d, generator=gen).to(DEV) * 8            # a sum of 16 latents
+    want = _f64(lin, ln, x, agg)
+    got = _run(fmt, lin, ln, x, agg).double()
+    exact = _run("fp32", lin, ln, x, agg).double()
+    scale = float(want.abs().max())
+    err, err_exact = float((got - want).abs().max()) / scale, float((exact - want).abs().max()) / scale
+    assert err <= 2e-6, (err, err_exact)
+    assert err <= 4 * err_exact + 2e-7, (err, err_exact)           # no worse than the true-f32 kernel's own rounding noise
+    assert float((got - want).norm() / want.norm()) <= 3e-7
+
+
+@pytest.mark.parametrize("fmt", ["fp32x3_n16", "fp16x2_n16"])
+def test_node_block_emulations_hold_over_value_scales(fmt):
+    """Weights of 1e-3 .. 10 and activations of 1e-4 .. 1e3 in one matrix: the two-term fp16 split scales its residual
+    by 2^11, so small values keep their bits (unscaled they would fall into fp16's subnormals)."""
+    n, d, nh = 2048, 128, 2
+    gen = torch.Generator().manual_seed(3)
+    lin, ln = _rand_node_mlp(gen, d, nh)
+    col = torch.logspace(-3, 1, d).to(DEV)
+    lin[0] = (lin[0][0] * torch.cat([col, col])[None, :], lin[0][1])       # per-input-column weight scale
+    row = torch.logspace(-4, 3, n)[:, None].to(DEV)
+    x = torch.randn(n, d, generator=gen).to(DEV) * row
+    agg = torch.randn(n, d, generator=gen).to(DEV) * row
+    want = _f64(lin, ln, x, agg, residual=False)
+    got = _run(fmt, lin, ln, x, agg, residual=False).double()
+    exact = _run("fp32", lin, ln, x, agg, residual=False).double()
+    err = (got - want).abs().amax(dim=1) / want.abs().amax(dim=1)          # per row: every scale counts
+    err_exact = (exact - want).abs().amax(dim=1) / want.abs().amax(dim=1)
+    assert float(err.max()) <= 5e-6, (float(err.max()), float(err_exact.max()))
+    assert float(err.max()) <= 4 * float(err_exact.max()) + 2e-7
+
+
+def test_fp16x2_overflow_is_loud():
+    """|activation| >= 65520 does not fit fp16: the row comes back non-finite, not as a wrong finite number; the other
+    rows are untouched."""
+    n, d = 64, 128
+    gen = torch.Generator().manual_seed(4)
+    lin, ln = _rand_node_mlp(gen, d, 2)
+    x = torch.randn(n, d, generator=gen).to(DEV)
+    agg = torch.randn(n, d, generator=gen).to(DEV)
+    x[5, 7] = 7.0e4
+    got = _run("fp16x2_n16", lin, ln, x, agg)
+    assert not torch.isfinite(got[5]).any()
+    keep = torch.ones(n, dtype=torch.bool, device=DEV)
+    keep[5] = False
+    want = _f64(lin, ln, x, agg)
+    assert torch.isfinite(got[keep]).all()
+    assert float((got[keep].double() - want[keep]).abs().max()) <= 2e-6 * float(want[keep].abs().max())
+    ok = _run("fp32x3_n16", lin, ln, x, agg)                                 # the bf16 form has the f32 range
+    assert torch.isfinite(ok).all()
+
+
+@pytest.mark.parametrize("fmt", ["fp32x3_n16", "fp16x2_n16"])
+@pytest.mark.parametrize("p_format", [_lib.P_BF16_S32, _lib.P_BF16_S16])
+def test_node_block_fused_projection_epilogue(fmt, p_format):
+    """next round's Ps / Pd written by the node kernel == cgnn_project_nodes on its output (same bf16 MFMA products)."""
+    n, d = 3000, 128
+    gen = torch.Generator().manual_seed(5)
+    lin, ln = _rand_node_mlp(gen, d, 2)
+    x = torch.randn(n, d, generator=gen).to(DEV)
+    agg = torch.randn(n, d, generator=gen).to(DEV) * 4
+    w1e = ((torch.rand(d, 3 * d, generator=gen) * 2 - 1) / np.sqrt(3 * d)).to(DEV)
+    b1e = ((torch.rand(d, generator=gen) * 2 - 1) / np.sqrt(3 * d)).to(DEV)
+    ws16, wd16 = ops.PackedLinear(w1e, None, "bf16_n16", 0, d), ops.PackedLinear(w1e, b1e, "bf16_n16", d, d)
+    w1, b1 = lin[0]
+    wx, wa = ops.PackedLinear(w1, b1, fmt, 0, d), ops.PackedLinear(w1, None, fmt, d, d)
+    mlp = ops.PackedMLP([(w1[:, :d].contiguous(), None)] + lin[1:], ln, fmt)
+    ps = torch.empty(n, d, dtype=torch.bfloat16, device=DEV)
+    pd = torch.empty_like(ps)
+    out = ops.node_block(mlp, wx, wa, x, agg, None, True, (ws16, wd16, ps, pd, p_format))
+    plain = ops.node_block(mlp, wx, wa, x, agg, None, True)
+    assert torch.equal(out, plain)
+    ws, wd = ops.PackedLinear(w1e, None, "bf16", 0, d), ops.PackedLinear(w1e, b1e, "bf16", d, d)
+    ps2, pd2 = ops.project_nodes(ws, wd, out, None, None, p_format)
+    torch.cuda.synchronize()
+    for a, b in ((ps, ps2), (pd, pd2)):
+        diff = (a.float() - b.float()).abs()
+        assert float(diff.max()) <= 2.0 ** -7 * float(b.float().abs().max())      # at most a bf16 rounding flip
+        assert float((diff > 0).float().mean()) < 0.02

@@ -294,12 +294,14 @@ def test_model_fp32_vs_reference_fixture(golden):
     assert rel_err(out["temp_rate"].cpu(), torch.from_numpy(g["temp_rate"])) <= TOL
 
 
-def test_model_fp32x3_node_path_meets_fp32_gate(golden):
+@pytest.mark.parametrize("node_precision", ["fp32x3", "fp16x2"])
+def test_model_emulated_f32_node_path_meets_fp32_gate(golden, node_precision):
     """node_precision="fp32x3": f32 emulated by three bf16 terms on the bf16 matrix cores (6 MFMAs per product
-    block).  It must hold the same 1e-5 gate as the exact-f32 kernels, against the reference fixtures."""
+    block); "fp16x2": by two fp16 terms (3 MFMAs).  Both must hold the same 1e-5 gate as the exact-f32 kernels,
+    against the reference fixtures."""
     g = golden
     with torch.no_grad():
-        out = _model(g, node_precision="fp32x3", edge_precision="bf16")(_graph(g))
+        out = _model(g, node_precision=node_precision, edge_precision="bf16")(_graph(g))
     assert rel_err(out["acceleration"].cpu(), torch.from_numpy(g["acceleration"])) <= TOL
     assert rel_err(out["temp_rate"].cpu(), torch.from_numpy(g["temp_rate"])) <= TOL
 
