@@ -54,7 +54,8 @@ def parse_args():
     p.add_argument("--hidden", type=int, default=None)
     p.add_argument("--mp-steps", type=int, default=None)
     p.add_argument("--hidden-layers", type=int, default=2)
-    p.add_argument("--edge-precision", default=None, choices=["bf16", "fp32"])
+    p.add_argument("--edge-precision", default=None, choices=["bf16", "fp32", "fp16x2"],
+                   help="fp16x2 = f32 accuracy from two fp16 terms on the matrix cores (latent = hidden = 128), else exact f32")
     p.add_argument("--node-precision", default=None, choices=["bf16", "fp32", "fp32x3", "fp16x2"],
                    help="f32 emulated on the matrix cores, both hold the 1e-5 gate: fp32x3 = three bf16 terms, six products; "
                         "fp16x2 = two fp16 terms, three products (half the matrix work; |activation| < 65504)")
@@ -73,7 +74,7 @@ def parse_args():
                    help="N > 1: also run the unsharded forward on rank 0 and compare (small sizes only)")
     a = p.parse_args()
     # BASELINE.json configs[0..4] (N, k, latent, rounds, edge / node arithmetic, seed 1234 + cfg)
-    presets = {"cfg1": (4096, 8, 64, 5, "fp32", "fp32", 1235, "weak"), "cfg2": (262144, 16, 128, 10, "fp32", "fp32", 1236, "weak"),
+    presets = {"cfg1": (4096, 8, 64, 5, "fp32", "fp32", 1235, "weak"), "cfg2": (262144, 16, 128, 10, "fp16x2", "fp16x2", 1236, "weak"),
                "cfg3": (1_000_000, 16, 128, 10, "bf16", "fp16x2", 1236, "weak"),
                "cfg4": (4_000_000, 16, 128, 10, "bf16", "fp16x2", 1238, "strong"),
                "cfg5": (1_000_000, 32, 256, 15, "bf16", "fp16x2", 1239, "strong")}
@@ -431,8 +432,13 @@ def main():
             alg_bytes = 2 * e_local * d * 4 + 2 * e_local * 4 + 2 * n_local * h * sz_p
             achieved = alg_bytes / (edge_ms * 1e-3) / 1e9
             n16 = args.edge_precision == "bf16" and d <= 128 and h <= 128
+            f2 = args.edge_precision == "fp16x2" and d == 128 and h == 128 and args.hidden_layers <= 3
             edge_kernel_name = (f"cgnn::edge_block_n16_kernel<{h // 32},{d // 32}>" if n16 else
-                                f"cgnn::edge_block_kernel<{args.edge_precision},{h // 32},{d // 32}>")
+                                f"cgnn::edge_block_f2ring_kernel<{args.hidden_layers}, false>" if f2 else
+                                f"cgnn::edge_block_kernel<{'fp32' if args.edge_precision == 'fp16x2' else args.edge_precision},"
+                                f"{h // 32},{d // 32}>")
+            if f2:      # f32 emulated by three fp16 products per element on the fp16 matrix cores
+                flops_exec, mfma_peak = 3.0 * flops_exec, MFMA_BF16_PEAK_TFLOPS
             roofline = {"kernel": edge_kernel_name, "bound": "hbm", "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": _traffic(f"edge_block:{n_local}:{k}:{d}:{args.edge_precision}", "cgnn::edge_block"),
@@ -441,7 +447,9 @@ def main():
                         "mfma": {"executed_tflops": round(flops_exec / (edge_ms * 1e-3) / 1e12, 1),
                                  "reference_equivalent_tflops": round(flops_alg / (edge_ms * 1e-3) / 1e12, 1),
                                  "peak_tflops": mfma_peak,
-                                 "frac_executed": round(flops_exec / (edge_ms * 1e-3) / 1e12 / mfma_peak, 4)}}
+                                 "frac_executed": round(flops_exec / (edge_ms * 1e-3) / 1e12 / mfma_peak, 4),
+                                 "note": ("fp16x2: three fp16 MFMA products per f32 product (executed flops = 3 x the f32 "
+                                          "count), priced against the dense 16-bit peak") if f2 else ""}}
         kernels = {name: {"calls": c, "avg_ms": round(ms / c, 4)} for name, (c, ms) in sorted(per_op.items())}
         if "aggregate" in per_op:
             c, ms = per_op["aggregate"]
@@ -468,7 +476,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "median_ms_synchronised": round(median_ms, 4),
             "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.edge_precision == "bf16" else "f32", "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp16x2": "f32 (two fp16 terms per operand, f32 accumulate)"}.get(args.edge_precision, "f32"),
+            "data": "synthetic",
             "config": {"workload": f"{'BASELINE ' + args.config + ': ' if args.config else ''}"
                                    f"{per_rank} particles/GPU ({per_rank * world} in all, {args.scaling} scaling) "
                                    f"uniform periodic box, k={k}, latent={d}, "

@@ -346,6 +346,10 @@ static int launch_edge(const MlpDev& m, size_t lds, const typename PRow<PREC>::e
     return check_hip(hipGetLastError(), "cgnn_edge_block launch");
 }
 
+int edge_block_f2(const MlpDev& m, const float* ps, const float* pd, const int32_t* src, const int32_t* dst,
+                  int64_t num_edges, const float* e_in, float* e_out, float* e_upd, int residual,
+                  hipStream_t st);   // edge_block_f2.hip
+
 }  // namespace cgnn
 
 using namespace cgnn;
@@ -393,6 +397,13 @@ extern "C" int cgnn_edge_block(const cgnn_mlp* mlp, const void* ps, const void* 
                       (long long)num_edges);
             return CGNN_ERR_UNSUPPORTED;
         }
+    }
+    if (prec == CGNN_F16X2_N16) {     // f32 accuracy on the fp16 matrix cores; Ps / Pd are CGNN_P_F32 tables
+        if (HT != 4 || DT != 4) {
+            set_error("cgnn_edge_block: CGNN_F16X2_N16 needs latent == hidden == 128 (got %d / %d)", latent, hidden);
+            return CGNN_ERR_UNSUPPORTED;
+        }
+        return edge_block_f2(m, (const float*)ps, (const float*)pd, src, dst, num_edges, e_in, e_out, e_upd, residual, st);
     }
     if (prec == CGNN_BF16_N16) {
         if (lds > CGNN_LDS_WEIGHT_BUDGET) {

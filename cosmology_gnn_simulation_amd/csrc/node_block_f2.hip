@@ -20,13 +20,12 @@
 // every store is issued by every wave -- and the <128 remaining rows go to the two-slot kernel).
 #include <string.h>
 
-#include "n16.hpp"
+#include "f2_ring.hpp"
 
 namespace cgnn {
 
 int num_compute_units();   // runtime.hip
 
-#define CGNN_F2R_BLOCK 512
 #define CGNN_F2R_MAX_UNITS 5      // hidden layers <= 3
 
 struct F2RingArgs {
@@ -46,63 +45,17 @@ struct F2RingArgs {
     int32_t residual;
 };
 
-typedef __attribute__((address_space(3))) f32x4* LdsF4Ptr;
-typedef __attribute__((address_space(3))) u32x4* LdsU4Ptr;
-typedef __attribute__((address_space(3))) bf16x4* LdsB4Ptr;
-
-namespace f2r {
-constexpr int D = 128, OT = 8, KS = 4;
-constexpr int CF = 8;                         // fragments per chunk: two output tiles x four k-steps
-constexpr int CHUNK = CF * 2048;              // 16 KiB
-constexpr int UNIT_CHUNKS = OT * KS / CF;     // 4
+namespace f2r_node {
 constexpr int NS = 5, PD = NS - 1;            // ring slots, chunks in flight ahead of the one being read
-constexpr int WAVES = CGNN_F2R_BLOCK / 64;
-constexpr int PC = CHUNK / 1024 / WAVES;      // 1-KiB DMA pieces per wave per chunk
-constexpr int VEC_BYTES = 4096;               // up to 8 vectors of 128 floats
-constexpr int PROJ_BYTES = 2 * OT * KS * 1024;
-constexpr int RING_OFF = VEC_BYTES + PROJ_BYTES;
-constexpr int LDS_BYTES = RING_OFF + NS * CHUNK;
-static_assert(PC * 1024 * WAVES == CHUNK, "a chunk is a whole number of pieces per wave");
-
-// one 1-KiB piece: 64 lanes x 16 B from sbase + voff to LDS address lds (wave-uniform) + lane * 16
-__device__ __forceinline__ void dma_piece(const char* sbase, unsigned voff, unsigned lds) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds)
-                 : "memory");
-}
-
-template <int IMM>
-__device__ __forceinline__ f32x4 row_load(const float* p) {
-    f32x4 r;
-    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r) : "v"(p), "n"(IMM) : "memory");
-    return r;
-}
-
-// the wait that hands the prefetched rows over: at most N younger vector-memory operations may still be in flight
-template <int N>
-__device__ __forceinline__ void rows_ready(f32x4 (&a)[OT], f32x4 (&b)[OT]) {
-    asm volatile("s_waitcnt vmcnt(%8)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
-                 : "n"(N)
-                 : "memory");
-    asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
-}
-}  // namespace f2r
-
-#ifdef CGNN_F2R_STAMPS   // developer build: cycle stamps of one workgroup's waves over one step (printed by the launcher)
-__device__ unsigned long long cgnn_f2r_stamps[8 * 64];
-#define F2R_STAMP(k)                                                             \
-    if (stamp_on && lane == 0) {                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                       \
-        cgnn_f2r_stamps[wave * 64 + (k)] = __builtin_readcyclecounter();         \
-        __builtin_amdgcn_sched_barrier(0);                                       \
-    }
-#else
-#define F2R_STAMP(k)
-#endif
+constexpr int PROJ_BYTES = 2 * f2r::OT * f2r::KS * 1024;
+constexpr int RING_OFF = f2r::VEC_BYTES + PROJ_BYTES;
+constexpr int LDS_BYTES = RING_OFF + NS * f2r::CHUNK;
+}  // namespace f2r_node
 
 template <int NH, int PFMT>
 __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2RingArgs a) {
     using namespace f2r;
+    using namespace f2r_node;
     constexpr int NU = NH + 2, NC = NU * UNIT_CHUNKS;
     static_assert(NU <= CGNN_F2R_MAX_UNITS, "too many layers");
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
@@ -170,57 +123,6 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
         const int64_t next_row = (next_step * WAVES + wave) * 16 + c;
 #endif
 
-        // timing-only ablations for scripts/ab (wrong results): -DCGNN_F2R_ABL_DMA / _BARRIER / _SPLIT / _LN / _PMFMA / _PSTORE
-#ifdef CGNN_F2R_ABL_DMA
-#define F2R_ISSUE(C, S)
-#else
-#define F2R_ISSUE(C, S) issue(C, S)
-#endif
-#ifdef CGNN_F2R_ABL_DMA
-#define F2R_CHUNK_WAIT(N)
-#else
-#define F2R_CHUNK_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
-#endif
-#ifdef CGNN_F2R_ABL_BARRIER
-#define F2R_BARRIER()
-#else
-#define F2R_BARRIER() asm volatile("s_barrier" ::: "memory")
-#endif
-#ifdef CGNN_F2R_ABL_SPLIT
-#define F2R_SPLIT(RELU, OP, SRC) asm volatile("" ::"v"(SRC[0][0]), "v"(SRC[OT - 1][3]))
-#else
-#define F2R_SPLIT(RELU, OP, SRC) operand16f2<RELU, KS>(OP, SRC)
-#endif
-        // Chunk Q of the step.  The barrier vouches for chunks Q and Q + 1 (so that the fragment reads can run into the
-        // next chunk), then chunk Q + PD starts into the slot chunk Q - 1 was read from.  Group g of the chunk is k-step g
-        // of its two output tiles; the reads of group g + 2 (of this chunk or the next) go out before group g's MFMAs.
-#define CGNN_F2R_CHUNK(Q, C0, C1, OP)                                                                               \
-    {                                                                                                               \
-        if ((Q) + 1 >= PD) F2R_CHUNK_WAIT((PD - 2) * PC);                                                            \
-        F2R_BARRIER();                                                                                               \
-        F2R_ISSUE(((Q) + PD) % NC, slot == 0 ? NS - 1 : slot - 1);                                                   \
-        const unsigned cur_ = ring_lds + slot * CHUNK + lane * 16;                                                   \
-        slot = slot + 1 == NS ? 0 : slot + 1;                                                                        \
-        const unsigned nxt_ = ring_lds + slot * CHUNK + lane * 16;                                                   \
-        constexpr int o0_ = 2 * ((Q) % UNIT_CHUNKS), g0_ = 4 * (Q);                                                  \
-        constexpr bool last_ = (Q) == NC - 1;                                                                        \
-        if ((Q) == 0) {                                                                                              \
-            pipe.template request<0, 0>(cur_);                                                                       \
-            pipe.template request<1, 1>(cur_);                                                                       \
-        }                                                                                                            \
-        pipe.template request<(g0_ + 2) % 3, 2>(cur_);                                                               \
-        pipe.template run<(g0_ + 0) % 3, 8, OT, KS>(C0, C1, OP, o0_, 0);                                             \
-        pipe.template request<(g0_ + 3) % 3, 3>(cur_);                                                               \
-        pipe.template run<(g0_ + 1) % 3, 8, OT, KS>(C0, C1, OP, o0_, 1);                                             \
-        if (!last_) pipe.template request<(g0_ + 4) % 3, 0>(nxt_);                                                   \
-        pipe.template run<(g0_ + 2) % 3, (last_ ? 4 : 8), OT, KS>(C0, C1, OP, o0_, 2);                               \
-        if (!last_) pipe.template request<(g0_ + 5) % 3, 1>(nxt_);                                                   \
-        pipe.template run<(g0_ + 3) % 3, (last_ ? 0 : 8), OT, KS>(C0, C1, OP, o0_, 3);                               \
-    }
-#define CGNN_F2R_UNIT(U, C0, C1, OP)                                                                   \
-    CGNN_F2R_CHUNK((U) * UNIT_CHUNKS + 0, C0, C1, OP) CGNN_F2R_CHUNK((U) * UNIT_CHUNKS + 1, C0, C1, OP) \
-    CGNN_F2R_CHUNK((U) * UNIT_CHUNKS + 2, C0, C1, OP) CGNN_F2R_CHUNK((U) * UNIT_CHUNKS + 3, C0, C1, OP)
-
 #ifdef CGNN_F2R_STAMPS
         const bool stamp_on = blockIdx.x == 9 && step == blockIdx.x + 3 * (int64_t)nb;
 #endif
@@ -264,8 +166,6 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
         fill16_global<OT>(c1, nullptr, q);
         CGNN_F2R_UNIT(NU - 1, c0, c1, op)
         F2R_STAMP(8);
-#undef CGNN_F2R_UNIT
-#undef CGNN_F2R_CHUNK
 
         // ---- tail: the next tile's rows are requested first, then LayerNorm, residual, stores, projections ----
         {
@@ -384,11 +284,11 @@ template <int NH, int PFMT>
 static int launch_f2ring(const F2RingArgs& a, hipStream_t st) {
     auto kern = node_block_f2ring_kernel<NH, PFMT>;
     int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, f2r::LDS_BYTES),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, f2r_node::LDS_BYTES),
                        "hipFuncSetAttribute(node_block_f2ring)");
     if (rc != CGNN_OK) return rc;
     const int grid = (int)(a.steps < (int64_t)num_compute_units() ? a.steps : (int64_t)num_compute_units());
-    kern<<<grid, CGNN_F2R_BLOCK, f2r::LDS_BYTES, st>>>(a);
+    kern<<<grid, CGNN_F2R_BLOCK, f2r_node::LDS_BYTES, st>>>(a);
 #ifdef CGNN_F2R_STAMPS
     {
         static int printed = 0;

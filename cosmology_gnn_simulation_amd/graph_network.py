@@ -228,8 +228,16 @@ class _PackedProcessor:
         if w1e.shape[1] != 3 * D or w1n.shape[1] != 2 * D:
             raise CgnnError(f"first-layer fan-in {w1e.shape[1]}/{w1n.shape[1]} does not match latent size {D}")
         # cat([x[src], x[dest], edge_attr]) -> [Ws | Wd | We]      (reference graph_network.py:89)
-        self.ws = ops.PackedLinear(w1e, None, edge_precision, 0, D)
-        self.wd = ops.PackedLinear(w1e, b1e, edge_precision, D, D)
+        if str(edge_precision).lower() in ("fp16x2", "f16x2", "fp32x3", "f32x3"):
+            # f32 accuracy on the matrix cores: the two-fp16-term edge kernel (latent = hidden = 128, <= 3 hidden layers,
+            # f32 Ps / Pd tables); other shapes take the exact-f32 kernels
+            e_lins = _split_mlp(net.edge_model)[0]
+            fits = D == 128 and w1e.shape[0] == 128 and len(e_lins) - 1 <= 3 and all(l.bias is not None for l in e_lins)
+            proj_precision, edge_precision = "fp32", ("fp16x2_n16" if fits else "fp32")
+        else:
+            proj_precision = edge_precision
+        self.ws = ops.PackedLinear(w1e, None, proj_precision, 0, D)
+        self.wd = ops.PackedLinear(w1e, b1e, proj_precision, D, D)
         self.edge = _pack_mlp(net.edge_model, edge_precision, first_layer_cols=(2 * D, D))
         # keep_32_row_edges: the model runs its edge stream through cgnn_edge_stream_run, which takes the 32-row packing
         if not keep_32_row_edges and self.edge.precision == _lib.BF16 and D <= 128 and self.edge.hidden <= 128 and \
