@@ -35,7 +35,7 @@ EXPORTS = (
     "cgnn_gather_rows", "cgnn_scatter_rows", "cgnn_tiled_rows", "cgnn_relayout", "cgnn_window_features",
     "cgnn_mlp_backward", "cgnn_weight_grad", "cgnn_col_dot", "cgnn_csr_workspace_bytes", "cgnn_csr_build",
     "cgnn_aggregate_csr", "cgnn_edge_stream", "cgnn_edge_stream_image_bytes", "cgnn_edge_stream_image_build",
-    "cgnn_edge_stream_run",
+    "cgnn_edge_stream_run", "cgnn_aggregate_plan_bytes", "cgnn_aggregate_plan_build", "cgnn_aggregate_planned",
 )
 ROWS, TILED32 = 0, 1
 
@@ -92,6 +92,10 @@ def load() -> C.CDLL:
     lib.cgnn_edge_stream_image_build.argtypes = [C.POINTER(Mlp), i32, C.POINTER(Mlp), i32, vp, sz, vp]
     lib.cgnn_edge_stream_run.argtypes = [vp, sz, i32, i32, i32, i32, vp, vp, i64, vp, vp, i64, vp, vp, vp, i32, vp]
     lib.cgnn_aggregate.argtypes = [vp, i32, vp, vp, i64, i32, i64, i32, vp, vp]
+    lib.cgnn_aggregate_plan_bytes.restype = sz
+    lib.cgnn_aggregate_plan_bytes.argtypes = [i64, i32]
+    lib.cgnn_aggregate_plan_build.argtypes = [vp, i64, i32, vp, vp]
+    lib.cgnn_aggregate_planned.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp]
     lib.cgnn_node_block.argtypes = [C.POINTER(Mlp), C.POINTER(Linear), C.POINTER(Linear), vp, vp, i64, vp, i32, i32,
                                     C.POINTER(Linear), C.POINTER(Linear), i32, vp, vp, i32, vp]
     lib.cgnn_knn_workspace_bytes.restype = sz

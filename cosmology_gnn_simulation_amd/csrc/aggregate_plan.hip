@@ -1,0 +1,289 @@
+// cgnn_aggregate for a graph that is used more than once (every message-passing round of a forward reads the same
+// receiver-sorted fixed-k edge list): a per-graph PLAN removes the repeated sender rows from the gather.
+//
+// reference graph_network.py:92 (PyG propagate, aggr='add', default message = sender node rows):
+//     out[i] = sum_{j < k} table[gather[i k + j]]
+//
+// cgnn_aggregate's fixed-k kernel reads k rows per receiver from L2: 16 M row gathers (8.2 GB) per round at cfg3, 13.7
+// TB/s of L2 -> CU traffic and 0.60 ms, although the receivers are in spatial (cell) order and neighbouring receivers
+// share most of their senders.  The plan cuts the receivers into blocks of 64 consecutive ones and stores, per block,
+// the list of DISTINCT sender rows (about 300 of the 1024 references at k = 16 on a uniform box) and, per edge, the
+// position of its sender in that list (uint16).  The kernel copies a block's distinct rows into LDS once (a 32-feature
+// slice at a time: up to 352 rows x 128 B) and every receiver sums its k neighbours from LDS, in the same order as
+// cgnn_aggregate (balanced tree for k = 8 / 16, left to right otherwise): results are bit-identical.
+//
+// A block with more than 352 distinct senders (strongly clustered particles, random graphs) gathers straight from memory
+// like the plain kernel.
+#include <type_traits>
+
+#include "cgnn_common.hpp"
+
+namespace cgnn {
+
+#define CGNN_AP_BLOCK_ROWS 64          // receivers per block
+#define CGNN_AP_MAX_UNIQUE 512         // distinct senders a block's list can hold
+#define CGNN_AP_STAGE_ROWS 352         // ... of which the kernel stages this many (two slices of them in flight in registers: 2 workgroups per CU); more: direct gather
+#define CGNN_AP_ROW_F4 9               // LDS row pitch in 16-byte units: 128 bytes of data + 16 of padding
+#define CGNN_AP_HASH 4096              // open-addressing table (>= 2 x the most keys a block can hold ... see build)
+#define CGNN_AP_THREADS 256
+#define CGNN_AP_MAX_K 32               // 64 x 32 = 2048 references per block
+
+// plan blob: [count: nblocks x int32, padded to 256 B][unique: nblocks x 512 x int32][local: num_edges x uint16]
+struct PlanView {
+    int32_t* count;
+    int32_t* unique;
+    uint16_t* local;
+};
+__host__ __device__ inline size_t plan_count_bytes(int64_t nblocks) { return (size_t)((nblocks * 4 + 255) / 256) * 256; }
+__host__ __device__ inline PlanView plan_view(void* blob, int64_t nblocks) {
+    PlanView v;
+    char* p = reinterpret_cast<char*>(blob);
+    v.count = reinterpret_cast<int32_t*>(p);
+    v.unique = reinterpret_cast<int32_t*>(p + plan_count_bytes(nblocks));
+    v.local = reinterpret_cast<uint16_t*>(p + plan_count_bytes(nblocks) + (size_t)nblocks * CGNN_AP_MAX_UNIQUE * 4);
+    return v;
+}
+
+__device__ __forceinline__ unsigned ap_hash(int32_t id) { return ((unsigned)id * 2654435761u) >> 20; }   // 12 bits
+
+// One workgroup per block: hash-deduplicate the block's sender ids, number the distinct ones by table position.
+__global__ __launch_bounds__(CGNN_AP_THREADS) void aggregate_plan_kernel(const int32_t* __restrict__ gather, int64_t num_nodes,
+                                                                         int k, PlanView plan) {
+    __shared__ int32_t keys[CGNN_AP_HASH];
+    __shared__ int32_t rank[CGNN_AP_HASH];
+    __shared__ int32_t wave_total[CGNN_AP_THREADS / 64];
+    const int64_t b = blockIdx.x;
+    const int64_t row0 = b * CGNN_AP_BLOCK_ROWS;
+    const int rows = (int)((num_nodes - row0) < CGNN_AP_BLOCK_ROWS ? (num_nodes - row0) : CGNN_AP_BLOCK_ROWS);
+    const int refs = rows * k;
+    const int32_t* g = gather + row0 * k;
+    for (int i = threadIdx.x; i < CGNN_AP_HASH; i += CGNN_AP_THREADS) keys[i] = -1;
+    __syncthreads();
+    for (int e = threadIdx.x; e < refs; e += CGNN_AP_THREADS) {
+        const int32_t id = g[e];
+        unsigned s = ap_hash(id);
+        for (;;) {
+            const int32_t old = atomicCAS(&keys[s], -1, id);
+            if (old == -1 || old == id) break;
+            s = (s + 1) & (CGNN_AP_HASH - 1);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the occupied slots: 16 consecutive slots per thread
+    constexpr int PER = CGNN_AP_HASH / CGNN_AP_THREADS;
+    int mine = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) mine += keys[threadIdx.x * PER + i] >= 0;
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d);
+        if ((int)(threadIdx.x & 63) >= d) incl += v;
+    }
+    if ((threadIdx.x & 63) == 63) wave_total[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int base = incl - mine;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wave_total[w];
+    int total = 0;
+    for (int w = 0; w < CGNN_AP_THREADS / 64; ++w) total += wave_total[w];
+    const bool fits = total <= CGNN_AP_MAX_UNIQUE;
+    int r = base;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int s = threadIdx.x * PER + i;
+        const int32_t id = keys[s];
+        if (id >= 0) {
+            rank[s] = r;
+            if (fits) plan.unique[b * CGNN_AP_MAX_UNIQUE + r] = id;
+            ++r;
+        }
+    }
+    if (threadIdx.x == 0) plan.count[b] = fits ? total : -1;
+    __syncthreads();
+    if (!fits) return;
+    for (int e = threadIdx.x; e < refs; e += CGNN_AP_THREADS) {
+        const int32_t id = g[e];
+        unsigned s = ap_hash(id);
+        while (keys[s] != id) s = (s + 1) & (CGNN_AP_HASH - 1);
+        plan.local[row0 * k + e] = (uint16_t)rank[s];
+    }
+}
+
+// One workgroup per block of 64 receivers; a 32-feature slice at a time through LDS.
+template <int K>   // 8, 16: unrolled balanced tree (cgnn_aggregate's order); 0: runtime k, left to right
+__global__ __launch_bounds__(CGNN_AP_THREADS) void aggregate_planned_kernel(const float* __restrict__ table,
+                                                                            const int32_t* __restrict__ gather, PlanView plan,
+                                                                            int krt, int64_t num_nodes, int width,
+                                                                            float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char ap_smem[];
+    typedef __attribute__((address_space(3))) f32x4* LdsF4;
+    const LdsF4 stage = (LdsF4)ap_smem;          // [unique][8] f32x4: 128 B per row
+    const int k = K ? K : krt;
+    const int64_t b = blockIdx.x;
+    const int64_t row0 = b * CGNN_AP_BLOCK_ROWS;
+    const int U = plan.count[b];
+    const int chunk = threadIdx.x & 7;            // 16-byte piece of the 128-byte slice
+    const int r_lo = threadIdx.x >> 3;            // receivers r_lo and r_lo + 32 of the block
+    const int slices = width / 32;
+    if (U < 0 || U > CGNN_AP_STAGE_ROWS) {   // too many distinct senders: the plain gather (same summation order)
+        for (int s = 0; s < slices; ++s)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int64_t row = row0 + r_lo + 32 * half;
+                if (row >= num_nodes) continue;
+                const int32_t* g = gather + row * k;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                if (K == 8 || K == 16) {
+                    f32x4 v[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (j < K) v[j] = *reinterpret_cast<const f32x4*>(table + (int64_t)g[j] * width + s * 32 + chunk * 4);
+                    const f32x4 h0 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                    acc = K == 16 ? h0 + (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15]))) : h0;
+                } else {
+                    for (int j = 0; j < k; ++j)
+                        acc += *reinterpret_cast<const f32x4*>(table + (int64_t)g[j] * width + s * 32 + chunk * 4);
+                }
+                __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(out + row * width + s * 32 + chunk * 4));
+            }
+        return;
+    }
+    // positions of this thread's two receivers' senders in the block's list (read once, used for every slice)
+    constexpr int KR = K ? K : CGNN_AP_MAX_K;
+    uint16_t li[2][KR];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int64_t row = row0 + r_lo + 32 * half;
+        const uint16_t* lp = plan.local + (row < num_nodes ? row : num_nodes - 1) * k;
+        if (K) {
+            const u32x4* lp4 = reinterpret_cast<const u32x4*>(lp);        // K * 2 bytes, 16-byte aligned (K = 8, 16)
+#pragma unroll
+            for (int w = 0; w < K / 8; ++w) {
+                const u32x4 v = lp4[w];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    li[half][8 * w + 2 * i] = (uint16_t)(v[i] & 0xffffu);
+                    li[half][8 * w + 2 * i + 1] = (uint16_t)(v[i] >> 16);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < KR; ++j) li[half][j] = j < k ? lp[j] : (uint16_t)0;
+        }
+    }
+    // The distinct rows of slice s + 1 travel to registers while slice s is summed from LDS: thread (r_lo, chunk) owns the
+    // 16-byte piece `chunk` of rows r_lo, r_lo + 32, ...  LDS rows are padded to 144 bytes so that the eight rows a wave
+    // reads at once do not all start on the same two banks.
+    constexpr int PASSES = CGNN_AP_STAGE_ROWS / 32;
+    const int32_t* uq = plan.unique + b * CGNN_AP_MAX_UNIQUE;
+    int32_t mine[PASSES];      // row ids (-1: none)
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) mine[i] = r_lo + 32 * i < U ? uq[r_lo + 32 * i] : -1;
+    const float* const tcol = table + chunk * 4;
+    // two slices in flight: slice s + 2 is requested when slice s has been copied to LDS
+    f32x4 pre[2][PASSES];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+        if (p < slices) {
+#pragma unroll
+            for (int i = 0; i < PASSES; ++i)
+                if (mine[i] >= 0) pre[p][i] = *reinterpret_cast<const f32x4*>(tcol + (int64_t)mine[i] * width + p * 32);
+        }
+    auto one_slice = [&](int s, auto parity) {
+        constexpr int P = decltype(parity)::value;
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i)
+            if (mine[i] >= 0) stage[(r_lo + 32 * i) * CGNN_AP_ROW_F4 + chunk] = pre[P][i];
+        __syncthreads();
+        if (s + 2 < slices) {
+#pragma unroll
+            for (int i = 0; i < PASSES; ++i)
+                if (mine[i] >= 0) pre[P][i] = *reinterpret_cast<const f32x4*>(tcol + (int64_t)mine[i] * width + (s + 2) * 32);
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int64_t row = row0 + r_lo + 32 * half;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (K == 8 || K == 16) {
+                f32x4 v[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (j < K) v[j] = stage[(int)li[half][j] * CGNN_AP_ROW_F4 + chunk];
+                const f32x4 h0 = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                acc = K == 16 ? h0 + (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15]))) : h0;
+            } else {
+#pragma unroll
+                for (int j = 0; j < KR; ++j)
+                    if (j < k) acc += stage[(int)li[half][j] * CGNN_AP_ROW_F4 + chunk];
+            }
+            if (row < num_nodes)
+                __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(out + row * width + s * 32 + chunk * 4));
+        }
+        __syncthreads();                            // everybody is done reading this slice
+    };
+    for (int s = 0; s < slices; s += 2) {
+        one_slice(s, std::integral_constant<int, 0>{});
+        if (s + 1 < slices) one_slice(s + 1, std::integral_constant<int, 1>{});
+    }
+}
+
+}  // namespace cgnn
+
+using namespace cgnn;
+
+extern "C" {
+
+size_t cgnn_aggregate_plan_bytes(int64_t num_nodes, int32_t fixed_k) {
+    if (num_nodes <= 0 || fixed_k <= 0 || fixed_k > CGNN_AP_MAX_K) return 0;
+    const int64_t nblocks = (num_nodes + CGNN_AP_BLOCK_ROWS - 1) / CGNN_AP_BLOCK_ROWS;
+    return plan_count_bytes(nblocks) + (size_t)nblocks * CGNN_AP_MAX_UNIQUE * 4 + (size_t)num_nodes * fixed_k * 2;
+}
+
+int cgnn_aggregate_plan_build(const int32_t* gather, int64_t num_nodes, int32_t fixed_k, void* plan, void* stream) {
+    if (!gather || !plan || num_nodes <= 0 || fixed_k <= 0) {
+        set_error("cgnn_aggregate_plan_build: invalid argument");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if (fixed_k > CGNN_AP_MAX_K) {
+        set_error("cgnn_aggregate_plan_build: fixed_k=%d above %d", fixed_k, CGNN_AP_MAX_K);
+        return CGNN_ERR_UNSUPPORTED;
+    }
+    const int64_t nblocks = (num_nodes + CGNN_AP_BLOCK_ROWS - 1) / CGNN_AP_BLOCK_ROWS;
+    aggregate_plan_kernel<<<(unsigned)nblocks, CGNN_AP_THREADS, 0, (hipStream_t)stream>>>(gather, num_nodes, fixed_k,
+                                                                                         plan_view(plan, nblocks));
+    return check_hip(hipGetLastError(), "cgnn_aggregate_plan_build launch");
+}
+
+int cgnn_aggregate_planned(const float* table, const int32_t* gather, const void* plan, int64_t num_nodes, int32_t fixed_k,
+                           int32_t width, float* out, void* stream) {
+    if (!table || !gather || !plan || !out || num_nodes < 0 || fixed_k <= 0 || width <= 0) {
+        set_error("cgnn_aggregate_planned: invalid argument");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if (width % 32 != 0 || fixed_k > CGNN_AP_MAX_K) {
+        set_error("cgnn_aggregate_planned: width %d must be a multiple of 32 and fixed_k %d <= %d", width, fixed_k,
+                  CGNN_AP_MAX_K);
+        return CGNN_ERR_UNSUPPORTED;
+    }
+    if (num_nodes == 0) return CGNN_OK;
+    const int64_t nblocks = (num_nodes + CGNN_AP_BLOCK_ROWS - 1) / CGNN_AP_BLOCK_ROWS;
+    const PlanView pv = plan_view(const_cast<void*>(plan), nblocks);
+    const int lds = CGNN_AP_STAGE_ROWS * CGNN_AP_ROW_F4 * 16;
+    hipStream_t st = (hipStream_t)stream;
+#define CGNN_AP_GO(Kk)                                                                                              \
+    {                                                                                                               \
+        auto kern = aggregate_planned_kernel<Kk>;                                                                   \
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds),                    \
+                           "hipFuncSetAttribute(aggregate_planned)");                                               \
+        if (rc != CGNN_OK) return rc;                                                                               \
+        kern<<<(unsigned)nblocks, CGNN_AP_THREADS, lds, st>>>(table, gather, pv, fixed_k, num_nodes, width, out);    \
+    }
+    if (fixed_k == 16) CGNN_AP_GO(16)
+    else if (fixed_k == 8) CGNN_AP_GO(8)
+    else CGNN_AP_GO(0)
+#undef CGNN_AP_GO
+    return check_hip(hipGetLastError(), "cgnn_aggregate_planned launch");
+}
+
+}  // extern "C"

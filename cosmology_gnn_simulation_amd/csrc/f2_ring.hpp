@@ -61,7 +61,7 @@ __device__ unsigned long long cgnn_f2r_stamps[8 * 64];
 #endif
 
 
-        // timing-only ablations for scripts/ab (wrong results): -DCGNN_F2R_ABL_DMA / _BARRIER / _SPLIT / _LN / _PMFMA / _PSTORE
+// timing-only ablations for scripts/ab (wrong results): -DCGNN_F2R_ABL_DMA / _BARRIER / _SPLIT / _LN / _PMFMA / _PSTORE
 #ifdef CGNN_F2R_ABL_DMA
 #define F2R_ISSUE(C, S)
 #else
@@ -82,9 +82,9 @@ __device__ unsigned long long cgnn_f2r_stamps[8 * 64];
 #else
 #define F2R_SPLIT(RELU, OP, SRC) operand16f2<RELU, KS>(OP, SRC)
 #endif
-        // Chunk Q of the step.  The barrier vouches for chunks Q and Q + 1 (so that the fragment reads can run into the
-        // next chunk), then chunk Q + PD starts into the slot chunk Q - 1 was read from.  Group g of the chunk is k-step g
-        // of its two output tiles; the reads of group g + 2 (of this chunk or the next) go out before group g's MFMAs.
+// Chunk Q of the step.  The barrier vouches for chunks Q and Q + 1 (so that the fragment reads can run into the next
+// chunk), then chunk Q + PD starts into the slot chunk Q - 1 was read from.  Group g of the chunk is k-step g of its two
+// output tiles; the reads of group g + 2 (of this chunk or the next) go out before group g's MFMAs.
 #define CGNN_F2R_CHUNK(Q, C0, C1, OP)                                                                               \
     {                                                                                                               \
         if ((Q) + 1 >= PD) F2R_CHUNK_WAIT((PD - 2) * PC);                                                            \

@@ -316,8 +316,8 @@ __device__ __forceinline__ float rows_sum(float s) {
 
 // LayerNorm over the 16 OT features of each edge; an edge's features live on lanes c, c+16, c+32, c+48.  Two passes
 // (mean, then centred squares) on whole f32x4 registers so that hipcc emits packed f32 instructions.
-template <int OT>
-__device__ __forceinline__ void layer_norm16(f32x4 (&a)[OT], LdsVecPtr gamma, LdsVecPtr beta, int q) {
+template <int OT, typename P = LdsVecPtr>
+__device__ __forceinline__ void layer_norm16(f32x4 (&a)[OT], P gamma, P beta, int q) {
     f32x4 s4 = a[0];
 #pragma unroll
     for (int o = 1; o < OT; ++o) s4 += a[o];
@@ -333,8 +333,8 @@ __device__ __forceinline__ void layer_norm16(f32x4 (&a)[OT], LdsVecPtr gamma, Ld
     const float rstd = 1.0f / sqrtf(v * (1.0f / (16 * OT)) + 1e-5f);
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
-        const f32x4 gm = *(LdsVec4Ptr)(gamma + 16 * o + 4 * q);
-        const f32x4 bt = *(LdsVec4Ptr)(beta + 16 * o + 4 * q);
+        const f32x4 gm = *(typename VecOf4<P>::type)(gamma + 16 * o + 4 * q);
+        const f32x4 bt = *(typename VecOf4<P>::type)(beta + 16 * o + 4 * q);
         a[o] = a[o] * (gm * rstd) + bt;
     }
 }

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(CGNN_NODE_N16_BLOCK) void node_block_f2n16_kernel(
         fold16f2<OT>(out, c1);
 #undef CGNN_F2_LAYER
 #undef CGNN_F2_CHUNK
-        layer_norm16_global<OT>(out, m.gamma, m.beta, q);
+        layer_norm16<OT, const float*>(out, m.gamma, m.beta, q);   // the ring kernel's arithmetic (node_block_f2.hip): same bits
 #pragma unroll
         for (int o = 0; o < OT; ++o) {
             if (residual) out[o] += xv[o];

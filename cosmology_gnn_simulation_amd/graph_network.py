@@ -290,7 +290,8 @@ def _run_round(p: _PackedProcessor, x: torch.Tensor, e: torch.Tensor, src, dst, 
         e_new = ops.edge_block(p.edge, ps, pd, src, dst, e, e_out, e_upd if message_source == "edge" else None,
                                residual)
         if message_source == "x_j":
-            agg = ops.aggregate(x, src, dst, n, fixed_k, src.numel(), agg)
+            agg = ops.aggregate(x, src, dst, n, fixed_k, src.numel(), agg,
+                                plan=ops.AggregatePlan.of(src, n, fixed_k, x.shape[1]))
         else:
             agg = ops.aggregate(e_upd, None, dst, n, fixed_k, src.numel(), agg)
     nxt = None
@@ -314,8 +315,9 @@ def _run_rounds_fused(rounds, x: torch.Tensor, e, src, dst, fixed_k: int, agg: O
     pd_all = torch.empty((L, n, H), dtype=torch.bfloat16, device=x.device)
     fmt = rounds[0].p_format
     ops.project_nodes(rounds[0].ws, rounds[0].wd, x, ps_all[0], pd_all[0], fmt)
+    plan = ops.AggregatePlan.of(src, n, fixed_k, x.shape[1])       # built once per graph, cached on its sender list
     for i, p in enumerate(rounds):
-        agg = ops.aggregate(x, src, dst, n, fixed_k, src.numel(), agg)
+        agg = ops.aggregate(x, src, dst, n, fixed_k, src.numel(), agg, plan=plan)
         nxt = None
         if i + 1 < L:
             q = rounds[i + 1]

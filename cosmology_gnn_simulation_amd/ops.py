@@ -407,10 +407,66 @@ def edge_stream_run(image: StreamImage, ps_all: torch.Tensor, pd_all: torch.Tens
     return e_out
 
 
+class AggregatePlan:
+    """Per-graph plan of the fixed-k aggregation (``cgnn_aggregate_plan_build``): per block of 64 receivers the distinct
+    sender rows and each edge's position among them, so that a round stages every distinct row once in LDS instead of
+    gathering it once per edge.  Valid for the ``gather`` tensor it was built from (kept alive here), in its version at
+    build time."""
+
+    MIN_NODES = 8192      # below this the plain gather is launch-bound either way
+
+    def __init__(self, gather: torch.Tensor, num_nodes: int, fixed_k: int):
+        gather = i32c(gather, "gather")
+        if gather.numel() != num_nodes * fixed_k:
+            raise CgnnError("AggregatePlan: gather must hold fixed_k senders per receiver")
+        nbytes = _lib.load().cgnn_aggregate_plan_bytes(num_nodes, fixed_k)
+        if nbytes == 0:
+            raise CgnnError(f"AggregatePlan: fixed_k={fixed_k} cannot be planned")
+        self.gather, self.num_nodes, self.fixed_k = gather, num_nodes, fixed_k
+        self.version = gather._version
+        self.blob = torch.empty(nbytes, dtype=torch.uint8, device=gather.device)
+        with _timed("aggregate_plan", gather.device):
+            check(_lib.load().cgnn_aggregate_plan_build(gather.data_ptr(), num_nodes, fixed_k, self.blob.data_ptr(),
+                                                        stream_ptr(gather.device)), "cgnn_aggregate_plan_build")
+
+    @staticmethod
+    def supported(num_nodes: int, fixed_k: int, width: int) -> bool:
+        return 0 < fixed_k <= 32 and width % 32 == 0 and num_nodes >= AggregatePlan.MIN_NODES
+
+    @staticmethod
+    def of(gather: torch.Tensor, num_nodes: int, fixed_k: int, width: int) -> Optional["AggregatePlan"]:
+        """The plan cached on ``gather`` (built on first use), or None where the planned kernel does not apply."""
+        if not AggregatePlan.supported(num_nodes, fixed_k, width) or gather.dtype != torch.int32 or not gather.is_cuda:
+            return None
+        plan = getattr(gather, "_cgnn_aggregate_plan", None)
+        if plan is None or plan.version != gather._version or plan.num_nodes != num_nodes or plan.fixed_k != fixed_k:
+            plan = AggregatePlan(gather, num_nodes, fixed_k)
+            gather._cgnn_aggregate_plan = plan
+        return plan
+
+
 def aggregate(table, gather: Optional[torch.Tensor], dst: Optional[torch.Tensor], num_nodes: int,
-              fixed_k: int = 0, num_edges: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              fixed_k: int = 0, num_edges: Optional[int] = None, out: Optional[torch.Tensor] = None,
+              plan: Optional[AggregatePlan] = None) -> torch.Tensor:
     """``out[i] = sum_{e: dst[e]==i} table[gather[e] if gather is not None else e]``.  ``table`` is a row-major
-    tensor, or a :class:`TiledRows` of per-edge messages (``gather`` must then be ``None``)."""
+    tensor, or a :class:`TiledRows` of per-edge messages (``gather`` must then be ``None``).  ``plan`` (for this
+    ``gather``): the planned fixed-k kernel, bit-identical results."""
+    if plan is not None:
+        table = f32c(table, "table")
+        if plan.gather is not gather and (gather is None or plan.gather.data_ptr() != gather.data_ptr()):
+            raise CgnnError("aggregate: the plan was built for another sender list")
+        if plan.version != plan.gather._version:
+            raise CgnnError("aggregate: the sender list changed after the plan was built")
+        if fixed_k != plan.fixed_k or num_nodes != plan.num_nodes or table.shape[1] % 32:
+            raise CgnnError("aggregate: the plan does not match this call")
+        if out is None:
+            out = torch.empty((num_nodes, table.shape[1]), dtype=torch.float32, device=table.device)
+        _same_device(table, plan.gather, plan.blob, out)
+        with _timed("aggregate", table.device):
+            check(_lib.load().cgnn_aggregate_planned(table.data_ptr(), plan.gather.data_ptr(), plan.blob.data_ptr(),
+                                                     num_nodes, fixed_k, table.shape[1], out.data_ptr(),
+                                                     stream_ptr(table.device)), "cgnn_aggregate_planned")
+        return out
     if isinstance(table, TiledRows):
         tb, layout, width, dev, nrows = table.buf, _lib.TILED32, table.width, table.device, table.n
     else:

@@ -177,6 +177,19 @@ int cgnn_aggregate(const float* table, int32_t table_layout, const int32_t* gath
                    int64_t num_edges, int32_t fixed_k, int64_t num_nodes, int32_t width,
                    float* out, void* stream);
 
+/* The same sum for a graph that is aggregated more than once (every round of a forward): a per-graph plan lists, for
+ * each block of 64 consecutive receivers, the DISTINCT sender rows and, per edge, its sender's position in that list; the
+ * kernel stages a block's distinct rows in LDS once and sums from there (about 3.4x fewer row reads at k = 16 on a
+ * spatially ordered graph).  Same summation order as cgnn_aggregate(fixed_k): bit-identical results.
+ *   gather   the receiver-sorted sender list, fixed_k per receiver (1 <= fixed_k <= 32); the plan is valid for exactly
+ *            this list (rebuild after any change)
+ *   plan     cgnn_aggregate_plan_bytes(num_nodes, fixed_k) bytes of device memory (0: not plannable)
+ *   width    multiple of 32; table is CGNN_ROWS.  reference graph_network.py:92 as above. */
+size_t cgnn_aggregate_plan_bytes(int64_t num_nodes, int32_t fixed_k);
+int cgnn_aggregate_plan_build(const int32_t* gather, int64_t num_nodes, int32_t fixed_k, void* plan, void* stream);
+int cgnn_aggregate_planned(const float* table, const int32_t* gather, const void* plan, int64_t num_nodes,
+                           int32_t fixed_k, int32_t width, float* out, void* stream);
+
 /* ---- K8+K9: fused node update --------------------------------------------------
  *   u = LayerNorm(MLP(cat[x, agg]))                          graph_network.py:94-96
  *   x_out = x + u (residual != 0, graph_network.py:181) or u

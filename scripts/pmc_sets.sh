@@ -22,7 +22,7 @@ for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
         agg[kn][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(kn, r["Counter_Name"])] += 1
 with open("$OUT/summary.txt", "w") as o:
     for kn, d in agg.items():
-        if any(t in kn for t in ("edge_block", "edge_stream", "aggregate", "node_block", "mlp_rows", "edge_encode", "knn_search", "project")):
+        if any(t in kn for t in ("edge_block", "edge_stream", "aggregate", "node_block", "mlp_rows", "edge_encode", "knn_search", "project", "f2ring")):
             o.write(kn + "\n")
             for c, v in sorted(d.items()):
                 o.write(f"   {c:40s} {v / cnt[(kn, c)]:18.1f}  (per dispatch, {cnt[(kn, c)]} dispatches)\n")

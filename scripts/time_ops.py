@@ -47,7 +47,7 @@ agg = ops.aggregate(x, src, dst, n, fk)
 
 
 def t(name, fn, nbytes=None, flops=None):
-    if a.only and a.only != name:
+    if a.only and not name.startswith(a.only):      # --only takes a prefix
         return
     for _ in range(2):
         fn()
@@ -94,6 +94,13 @@ if a.edge_precision == "bf16" and (not a.only or a.only.startswith("edge_stream"
 t("edge_block", lambda: ops.edge_block(p.edge, ps, pd, src, dst, e, e, None, True),
   2 * E * d * 4 + 2 * E * 4 + 2 * n * d * 4, 6.0 * E * d * d)
 t("aggregate x_j", lambda: ops.aggregate(x, src, dst, n, fk, E, agg), E * d * 4 + E * 4 + n * d * 4)
+if ops.AggregatePlan.supported(n, fk, d) and (not a.only or a.only.startswith("aggregate")):
+    t("aggregate_plan", lambda: ops.AggregatePlan(src, n, fk))
+    plan_ = ops.AggregatePlan(src, n, fk)
+    cnt_ = plan_.blob[: 4 * ((n + 63) // 64)].view(torch.int32).float()
+    print(f"   (plan: {float(cnt_.clamp(min=0).mean()):.0f} distinct rows per block of 64 receivers x k = {64 * fk} references, "
+          f"{int((cnt_ < 0).sum())} blocks over the limit)")
+    t("aggregate planned", lambda: ops.aggregate(x, src, dst, n, fk, E, agg, plan=plan_), E * d * 4 + E * 4 + n * d * 4)
 # general scatter-add (fixed_k = 0): receiver-sorted list (one atomic row per receiver) and a shuffled one (one per edge);
 # GB/s = table rows read + atomic bytes added
 if not a.only or a.only == "aggregate_atomic":
