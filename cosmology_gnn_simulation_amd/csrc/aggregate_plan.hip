@@ -119,7 +119,11 @@ __global__ __launch_bounds__(CGNN_AP_THREADS) void aggregate_planned_kernel(cons
     typedef __attribute__((address_space(3))) f32x4* LdsF4;
     const LdsF4 stage = (LdsF4)ap_smem;          // [unique][8] f32x4: 128 B per row
     const int k = K ? K : krt;
-    const int64_t b = blockIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): XCD x takes the x-th contiguous eighth of
+    // the blocks, so that neighbouring blocks -- which share senders -- meet in one L2 (placement only affects speed).
+    const int64_t nblk = gridDim.x, per = nblk >> 3, rem = nblk & 7;
+    const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int64_t b = xcd * per + (xcd < rem ? xcd : rem) + slot;
     const int64_t row0 = b * CGNN_AP_BLOCK_ROWS;
     const int U = plan.count[b];
     const int chunk = threadIdx.x & 7;            // 16-byte piece of the 128-byte slice

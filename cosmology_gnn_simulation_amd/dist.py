@@ -342,7 +342,7 @@ class ShardedForward:
                 ops.aggregate(self.e_upd, None, sh.dst_local, sh.n_owned, sh.k, sh.src_local.numel(), self.agg)
             else:
                 ops.aggregate(self.x_all, sh.src_local, sh.dst_local, sh.n_owned, sh.k, sh.src_local.numel(),
-                              self.agg)
+                              self.agg, plan=ops.AggregatePlan.of(sh.src_local, sh.n_owned, sh.k, self.x_all.shape[1]))
         nxt = None
         if i + 1 < len(rounds):
             q = rounds[i + 1]
@@ -351,6 +351,14 @@ class ShardedForward:
                 nxt = (q.ws_fused if fused_ok else q.ws, q.wd_fused if fused_ok else q.wd, ps_own, self.pd, q.p_format)
         ops.node_block(p.node, p.wx, p.wa, x_own, self.agg, x_own, True, nxt)
         self._projected = nxt is not None
+
+    def _src_part(self, a: int, b: int) -> torch.Tensor:
+        """The sender list of owned receivers [a, b) as one tensor OBJECT per part (the aggregation plan is cached on it)."""
+        parts = self.__dict__.setdefault("_src_parts", {})
+        if (a, b) not in parts:
+            k = self.sh.k
+            parts[(a, b)] = self.sh.src_local[a * k:b * k]
+        return parts[(a, b)]
 
     def _round_nodes(self, i: int, part: str = "all"):
         """Fused mode: the node half of round ``i`` for the owned rows of ``part``: ``"interior"`` (receivers whose
@@ -368,7 +376,9 @@ class ShardedForward:
             x_in = self.x_all[a:b]
             if i == 0:
                 ops.project_nodes(p.ws, p.wd, x_in, self.ps[0][a:b], self.pd[0][a:b], p.p_format)
-            ops.aggregate(self.x_all, sh.src_local[a * k:b * k], None, b - a, k, (b - a) * k, self.agg[a:b])
+            src_part = self._src_part(a, b)
+            ops.aggregate(self.x_all, src_part, None, b - a, k, (b - a) * k, self.agg[a:b],
+                          plan=ops.AggregatePlan.of(src_part, b - a, k, self.x_all.shape[1]))
             nxt = None
             if i + 1 < len(rounds):
                 q = rounds[i + 1]

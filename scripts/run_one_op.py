@@ -13,7 +13,7 @@ if os.environ.get("CGNN_LIB_PATH"):      # developer A/B: time another build of 
 from cosmology_gnn_simulation_amd import data_utils, graph_network, ops, synthetic  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("op", choices=["edge_block", "edge_stream", "aggregate", "node_block", "node_block_proj", "project_nodes", "enc_edge", "knn"])
+ap.add_argument("op", choices=["edge_block", "edge_stream", "aggregate", "aggregate_planned", "scatter_shuffled", "node_block", "node_block_proj", "project_nodes", "enc_edge", "knn"])
 ap.add_argument("--particles", type=int, default=1_000_000)
 ap.add_argument("--neighbors", type=int, default=16)
 ap.add_argument("--latent", type=int, default=128)
@@ -70,7 +70,14 @@ if a.op == "node_block_proj":     # the node block as the fused forward runs it:
     m2.edge_precision, m2.node_precision = a.edge_precision, a.node_precision
     r0, r1 = m2._pack(17, 4)["rounds"]
     ps2, pd2 = ops.project_nodes(r1.ws, r1.wd, x, None, None, r1.p_format)
+if a.op == "aggregate_planned":
+    plan_ = ops.AggregatePlan(src, n, fk)
+if a.op == "scatter_shuffled":      # general edge list (fixed_k = 0), shuffled: one float atomic row per edge
+    perm_ = torch.randperm(n * k, device=dev, generator=gen)
+    src_sh, dst_sh = src[perm_].contiguous(), dst[perm_].contiguous()
 fn = {
+    "aggregate_planned": lambda: ops.aggregate(x, src, dst, n, fk, n * k, agg, plan=plan_),
+    "scatter_shuffled": lambda: ops.aggregate(x, src_sh, dst_sh, n, 0, n * k, agg),
     "node_block_proj": lambda: ops.node_block(r0.node, r0.wx, r0.wa, x, agg, x, True,
                                               (r1.ws_fused, r1.wd_fused, ps2, pd2, r1.p_format)),
     "edge_stream": lambda: (ops.edge_stream_run(imageL, ps_all, pd_all, src, dst, None if imageL.enc_in else e, e,
