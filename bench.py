@@ -432,8 +432,10 @@ def main():
             alg_bytes = 2 * e_local * d * 4 + 2 * e_local * 4 + 2 * n_local * h * sz_p
             achieved = alg_bytes / (edge_ms * 1e-3) / 1e9
             n16 = args.edge_precision == "bf16" and d <= 128 and h <= 128
+            ring256 = args.edge_precision == "bf16" and d == 256 and h == 256 and args.hidden_layers <= 3
             f2 = args.edge_precision == "fp16x2" and d == 128 and h == 128 and args.hidden_layers <= 3
             edge_kernel_name = (f"cgnn::edge_block_n16_kernel<{h // 32},{d // 32}>" if n16 else
+                                f"cgnn::edge_block_ring256_kernel<{args.hidden_layers}, false>" if ring256 else
                                 f"cgnn::edge_block_f2ring_kernel<{args.hidden_layers}, false>" if f2 else
                                 f"cgnn::edge_block_kernel<{'fp32' if args.edge_precision == 'fp16x2' else args.edge_precision},"
                                 f"{h // 32},{d // 32}>")

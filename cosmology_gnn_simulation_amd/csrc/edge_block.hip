@@ -346,6 +346,9 @@ static int launch_edge(const MlpDev& m, size_t lds, const typename PRow<PREC>::e
     return check_hip(hipGetLastError(), "cgnn_edge_block launch");
 }
 
+int edge_block_ring256(const MlpDev& m, const __bf16* ps, const __bf16* pd, const int32_t* src, const int32_t* dst,
+                       int64_t num_edges, const float* e_in, float* e_out, float* e_upd, int residual,
+                       hipStream_t st);   // edge_block_ring256.hip
 int edge_block_f2(const MlpDev& m, const float* ps, const float* pd, const int32_t* src, const int32_t* dst,
                   int64_t num_edges, const float* e_in, float* e_out, float* e_upd, int residual,
                   hipStream_t st);   // edge_block_f2.hip
@@ -404,6 +407,14 @@ extern "C" int cgnn_edge_block(const cgnn_mlp* mlp, const void* ps, const void* 
             return CGNN_ERR_UNSUPPORTED;
         }
         return edge_block_f2(m, (const float*)ps, (const float*)pd, src, dst, num_edges, e_in, e_out, e_upd, residual, st);
+    }
+    if (prec == CGNN_BF16_N16 && HT == 8 && DT == 8) {   // latent = hidden = 256: weights streamed through an LDS ring
+        if (agg_out != nullptr) {
+            set_error("cgnn_edge_block: the 256-wide CGNN_BF16_N16 kernel has no fused aggregation (use cgnn_aggregate)");
+            return CGNN_ERR_UNSUPPORTED;
+        }
+        return edge_block_ring256(m, (const __bf16*)ps, (const __bf16*)pd, src, dst, num_edges, e_in, e_out, e_upd, residual,
+                                  st);
     }
     if (prec == CGNN_BF16_N16) {
         if (lds > CGNN_LDS_WEIGHT_BUDGET) {

@@ -1,0 +1,339 @@
+// cgnn_edge_block, CGNN_BF16_N16 weights, latent = hidden = 256 (BASELINE cfg5; reference README.md:59-62 allows latent
+// sizes up to 256): one round's edge update
+//
+//   e' = e + LayerNorm(W3 relu(W2 relu(Ps[src] + Pd[dst] + We e) + b2) + b3)          graph_network.py:89-90, :182
+//
+// with bf16 operands, f32 accumulation, f32 LayerNorm and residual -- the arithmetic of edge_block_n16_kernel
+// (edge_block.hip), whose weights must be LDS resident: at 256 a layer is 128 KiB, three of them 384 KiB.  Here the
+// layers stream through an eight-slot LDS ring of 16-KiB chunks (two 16-feature output tiles over K = 256) exactly as in
+// edge_block_f2.hip / node_block_f2.hip (LDS-DMA seven chunks ahead, counted vmcnt waits, raw s_barrier per chunk, LDS
+// fragment reads one MFMA group ahead across chunk boundaries).  16 edges per wave (v_mfma_f32_16x16x32_bf16), eight
+// waves per workgroup (two per SIMD), 128 edges per step; the P rows (CGNN_P_BF16_S16) enter the accumulators through
+// selector MFMAs.  Before this kernel the 256-wide edge update ran on the 32-row kernel with its weights read from L2 by
+// every wave: 50.6 ms per round at cfg5's shape (32 M edges), a tenth of the MFMA peak.
+//
+// Registers set the order of the tail: 64 each for the accumulators, the f32 tile kept for the residual and the next
+// tile's prefetch do not leave room for its P rows (32 + 32) as well, so the next tile's latents are requested first
+// (into the registers the operand and the fragment pipeline have just vacated) and its P rows are requested one by one
+// behind the stores, as the stores release the accumulator and tile registers.
+#include <string.h>
+
+#include "n16.hpp"
+
+namespace cgnn {
+
+int num_compute_units();   // runtime.hip
+
+#define CGNN_R256_BLOCK 512
+#define CGNN_R256_MAX_UNITS 4      // hidden layers <= 3
+
+struct Ring256Args {
+    const char* unit[CGNN_R256_MAX_UNITS];   // packed CGNN_BF16_N16: We (the e third of Linear 0), hidden..., output
+    const float* bias[CGNN_R256_MAX_UNITS];  // bias[l] of Linear l = 1 .. nh (Linear 0's lives in Pd)
+    const float* gamma;
+    const float* beta;
+    const __bf16* ps;                        // [n, 256] CGNN_P_BF16_S16
+    const __bf16* pd;
+    const int32_t* src;
+    const int32_t* dst;
+    const float* e_in;                       // CGNN_TILED32
+    float* e_out;
+    float* e_upd;
+    int64_t num_edges;
+    int64_t first_half_tile;
+    int64_t half_tiles;
+    int64_t steps;
+    int32_t residual;
+};
+
+namespace r256 {
+constexpr int D = 256, OT = 16, KS = 8;
+constexpr int CF = 16;                        // fragments per chunk: two output tiles x eight k-steps
+constexpr int CHUNK = CF * 1024;              // 16 KiB
+constexpr int UNIT_CHUNKS = OT * KS / CF;     // 8
+constexpr int NS = 8, PD = NS - 1;
+constexpr int WAVES = CGNN_R256_BLOCK / 64;
+constexpr int PC = CHUNK / 1024 / WAVES;
+constexpr int VEC_BYTES = 8192;               // up to 8 vectors of 256 floats
+constexpr int RING_OFF = VEC_BYTES;
+constexpr int LDS_BYTES = RING_OFF + NS * CHUNK;    // 136 KiB
+
+__device__ __forceinline__ void dma_piece(const char* sbase, unsigned voff, unsigned lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds)
+                 : "memory");
+}
+template <int IMM>
+__device__ __forceinline__ u32x4 load16(const void* p) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r) : "v"(p), "n"(IMM) : "memory");
+    return r;
+}
+__device__ __forceinline__ int idx_load(const int32_t* p) {
+    int r;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+// the wait that hands the prefetched tile over: at most N younger vector-memory operations may still be in flight
+template <int N>
+__device__ __forceinline__ void tile_ready(u32x4 (&e)[OT], u32x4 (&a)[KS], u32x4 (&b)[KS], int& s, int& d) {
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]), "+v"(e[6]), "+v"(e[7])
+                 : "n"(N)
+                 : "memory");
+    asm volatile("" : "+v"(e[8]), "+v"(e[9]), "+v"(e[10]), "+v"(e[11]), "+v"(e[12]), "+v"(e[13]), "+v"(e[14]), "+v"(e[15]));
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+    asm volatile(""
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(s),
+                   "+v"(d));
+}
+
+// LDS fragment pipeline: a chunk holds [tile 0: k-steps 0..7][tile 1: k-steps 0..7]; a group = two k-steps of both tiles
+struct FragPipe {
+    u32x4 buf[2][4];     // [group % 2][(t0, 2G), (t0, 2G+1), (t1, 2G), (t1, 2G+1)]: one group ahead (registers)
+    template <int SLOT, int G>
+    __device__ __forceinline__ void request(unsigned addr) {
+        buf[SLOT][0] = lds_read_b128<(0 * KS + 2 * G) * 1024>(addr);
+        buf[SLOT][1] = lds_read_b128<(0 * KS + 2 * G + 1) * 1024>(addr);
+        buf[SLOT][2] = lds_read_b128<(1 * KS + 2 * G) * 1024>(addr);
+        buf[SLOT][3] = lds_read_b128<(1 * KS + 2 * G + 1) * 1024>(addr);
+    }
+    template <int SLOT, int NEWER>
+    __device__ __forceinline__ void run(f32x4 (&c)[OT], const bf16x8 (&in)[KS], int o0, int g) {
+        lds_wait4<NEWER>(buf[SLOT][0], buf[SLOT][1], buf[SLOT][2], buf[SLOT][3]);
+        c[o0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, buf[SLOT][0]), in[2 * g], c[o0], 0, 0, 0);
+        c[o0 + 1] =
+            __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, buf[SLOT][2]), in[2 * g], c[o0 + 1], 0, 0, 0);
+        c[o0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, buf[SLOT][1]), in[2 * g + 1], c[o0], 0, 0, 0);
+        c[o0 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, buf[SLOT][3]), in[2 * g + 1], c[o0 + 1],
+                                                            0, 0, 0);
+    }
+};
+}  // namespace r256
+
+// Chunk Q of the step (see f2_ring.hpp for the protocol): the barrier vouches for chunks Q and Q + 1, chunk Q + PD starts
+// into the slot chunk Q - 1 was read from, the reads of group g + 1 go out before group g's MFMAs.
+#define CGNN_R256_CHUNK(Q, C, OP)                                                                                   \
+    {                                                                                                               \
+        if ((Q) + 1 >= PD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 2) * PC) : "memory");                      \
+        asm volatile("s_barrier" ::: "memory");                                                                      \
+        issue(((Q) + PD) % NC, slot == 0 ? NS - 1 : slot - 1);                                                       \
+        const unsigned cur_ = ring_lds + slot * CHUNK + lane * 16;                                                   \
+        slot = slot + 1 == NS ? 0 : slot + 1;                                                                        \
+        const unsigned nxt_ = ring_lds + slot * CHUNK + lane * 16;                                                   \
+        constexpr int o0_ = 2 * ((Q) % UNIT_CHUNKS);                                                                 \
+        constexpr bool last_ = (Q) == NC - 1;                                                                        \
+        if ((Q) == 0) pipe.template request<0, 0>(cur_);                                                             \
+        pipe.template request<1, 1>(cur_);                                                                           \
+        pipe.template run<0, 4>(C, OP, o0_, 0);                                                                      \
+        pipe.template request<0, 2>(cur_);                                                                           \
+        pipe.template run<1, 4>(C, OP, o0_, 1);                                                                      \
+        pipe.template request<1, 3>(cur_);                                                                           \
+        pipe.template run<0, 4>(C, OP, o0_, 2);                                                                      \
+        if (!last_) pipe.template request<0, 0>(nxt_);                                                               \
+        pipe.template run<1, (last_ ? 0 : 4)>(C, OP, o0_, 3);                                                        \
+    }
+#define CGNN_R256_UNIT(U, C, OP)                                                                               \
+    CGNN_R256_CHUNK((U) * 8 + 0, C, OP) CGNN_R256_CHUNK((U) * 8 + 1, C, OP) CGNN_R256_CHUNK((U) * 8 + 2, C, OP)  \
+    CGNN_R256_CHUNK((U) * 8 + 3, C, OP) CGNN_R256_CHUNK((U) * 8 + 4, C, OP) CGNN_R256_CHUNK((U) * 8 + 5, C, OP)  \
+    CGNN_R256_CHUNK((U) * 8 + 6, C, OP) CGNN_R256_CHUNK((U) * 8 + 7, C, OP)
+
+template <int NH, bool RAGGED>
+__global__ __launch_bounds__(CGNN_R256_BLOCK) void edge_block_ring256_kernel(Ring256Args a) {
+    using namespace r256;
+    constexpr int NU = NH + 1, NC = NU * UNIT_CHUNKS;
+    static_assert(NU <= CGNN_R256_MAX_UNITS && UNIT_CHUNKS == 8, "layer count / chunking");
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    {   // resident: bias of Linear 1 .. NH at vec[l], LayerNorm vectors behind them
+        float* vec = reinterpret_cast<float*>(cgnn_smem);
+        for (int i = threadIdx.x; i < D; i += blockDim.x) {
+#pragma unroll
+            for (int l = 1; l <= NH; ++l) vec[l * D + i] = a.bias[l][i];
+            vec[(NH + 1) * D + i] = a.gamma[i];
+            vec[(NH + 2) * D + i] = a.beta[i];
+        }
+    }
+    __syncthreads();
+    const LdsVecPtr vec = (LdsVecPtr)cgnn_smem;
+    const unsigned ring_lds = (unsigned)(uintptr_t)(cgnn_smem + RING_OFF);
+    const bf16x8 sel0 = p16_selector(lane, 0), sel1 = p16_selector(lane, 1);
+
+    const unsigned voff = (unsigned)wave * 1024u + (unsigned)lane * 16u;
+    int slot = 0;
+    auto issue = [&](int chunk, int into_slot) {
+        const char* src = a.unit[chunk / UNIT_CHUNKS] + (chunk % UNIT_CHUNKS) * CHUNK;
+#pragma unroll
+        for (int i = 0; i < PC; ++i)
+            dma_piece(src + i * (WAVES * 1024), voff, ring_lds + into_slot * CHUNK + (wave + WAVES * i) * 1024);
+    };
+#pragma unroll
+    for (int i = 0; i < PD; ++i) issue(i, i);
+
+    const int64_t last_ht = a.half_tiles - 1;
+    auto edge_of = [&](int64_t ht) {
+        const int64_t e = ht * 16 + c;
+        return e < a.num_edges ? e : a.num_edges - 1;
+    };
+    auto tile_offset = [&](int64_t ht) { return (ht >> 1) * (32 * D) + n16_lane_offset(c, q, (int)(ht & 1)); };
+    auto clip = [&](int64_t ht) { return RAGGED && ht > last_ht ? last_ht : ht; };
+
+    const int nb = gridDim.x;
+    int64_t step = blockIdx.x;
+    u32x4 en[OT], psn[KS], pdn[KS];
+    int sn, dn;
+    {
+        const int64_t ht = clip(a.first_half_tile + step * WAVES + wave);
+        const int64_t ec = edge_of(ht);
+        int s0 = idx_load(a.src + ec), d0 = idx_load(a.dst + ec);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(s0), "+v"(d0)::"memory");
+        const float* ep = a.e_in + tile_offset(ht);
+        const __bf16* pp = a.ps + (int64_t)s0 * D + 8 * q;
+        const __bf16* dp = a.pd + (int64_t)d0 * D + 8 * q;
+        static_for_each([&](auto oc) { en[decltype(oc)::value] = load16<0>(ep + n16_tile_offset(decltype(oc)::value)); },
+                        std::make_integer_sequence<int, OT>{});
+        static_for_each([&](auto sc) { psn[decltype(sc)::value] = load16<decltype(sc)::value * 64>(pp); },
+                        std::make_integer_sequence<int, KS>{});
+        static_for_each([&](auto sc) { pdn[decltype(sc)::value] = load16<decltype(sc)::value * 64>(dp); },
+                        std::make_integer_sequence<int, KS>{});
+        const int64_t nstep = step + nb < a.steps ? step + nb : step;
+        const int64_t ec1 = edge_of(clip(a.first_half_tile + nstep * WAVES + wave));
+        sn = idx_load(a.src + ec1);
+        dn = idx_load(a.dst + ec1);
+        tile_ready<0>(en, psn, pdn, sn, dn);
+    }
+
+    for (; step < a.steps; step += nb) {
+        const int64_t ht_raw = a.first_half_tile + step * WAVES + wave;
+        const bool valid = !RAGGED || ht_raw <= last_ht;           // wave-uniform
+        const int64_t ht = clip(ht_raw);
+        const int64_t next_step = step + nb < a.steps ? step + nb : step;
+        const int64_t next2_step = next_step + nb < a.steps ? next_step + nb : next_step;
+        const int64_t ht1 = clip(a.first_half_tile + next_step * WAVES + wave);
+        const int64_t ec2 = edge_of(clip(a.first_half_tile + next2_step * WAVES + wave));
+
+        FragPipe pipe;
+        f32x4 ev[OT], acc[OT];
+        bf16x8 op[KS];
+#pragma unroll
+        for (int o = 0; o < OT; ++o) ev[o] = __builtin_bit_cast(f32x4, en[o]);
+        {
+            bf16x8 pso[KS], pdo[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                pso[s] = __builtin_bit_cast(bf16x8, psn[s]);
+                pdo[s] = __builtin_bit_cast(bf16x8, pdn[s]);
+            }
+            p16_accumulate<KS>(acc, pso, pdo, sel0, sel1);      // Linear 0's node thirds (+ b1)
+        }
+        operand16<false, KS>(op, ev);
+        CGNN_R256_UNIT(0, acc, op)
+        operand16<true, KS>(op, acc);
+        if constexpr (NH >= 2) {
+            fill16<OT>(acc, vec + 1 * D, q);
+            CGNN_R256_UNIT(1, acc, op)
+            operand16<true, KS>(op, acc);
+        }
+        if constexpr (NH >= 3) {
+            fill16<OT>(acc, vec + 2 * D, q);
+            CGNN_R256_UNIT(2, acc, op)
+            operand16<true, KS>(op, acc);
+        }
+        fill16<OT>(acc, vec + NH * D, q);
+        CGNN_R256_UNIT(NU - 1, acc, op)
+
+        // ---- tail ----
+        const __bf16* pp = a.ps + (int64_t)sn * D + 8 * q;      // the next tile's P rows (indices from a step ago)
+        const __bf16* dp = a.pd + (int64_t)dn * D + 8 * q;
+        sn = idx_load(a.src + ec2);                             // indices of the tile after it
+        dn = idx_load(a.dst + ec2);
+        {
+            const float* ep = a.e_in + tile_offset(ht1);
+            static_for_each([&](auto oc) { en[decltype(oc)::value] = load16<0>(ep + n16_tile_offset(decltype(oc)::value)); },
+                            std::make_integer_sequence<int, OT>{});
+        }
+        layer_norm16<OT>(acc, vec + (NH + 1) * D, vec + (NH + 2) * D, q);
+        const int64_t tb = tile_offset(ht);
+        if (valid && a.e_upd != nullptr) {   // block-uniform pointer
+#pragma unroll
+            for (int o = 0; o < OT; ++o) *reinterpret_cast<f32x4*>(a.e_upd + tb + n16_tile_offset(o)) = acc[o];
+        }
+        // stores and the next tile's P-row requests alternate (a store releases the registers the next request lands in);
+        // the last request goes out before the last store, so that the closing wait can leave that store in flight
+        static_for_each([&](auto oc) {
+            constexpr int o = decltype(oc)::value;
+            if constexpr (o == OT - 1) pdn[KS - 1] = load16<(KS - 1) * 64>(dp);
+            if (a.residual) acc[o] += ev[o];
+            if (valid) *reinterpret_cast<f32x4*>(a.e_out + tb + n16_tile_offset(o)) = acc[o];
+            if constexpr (o < KS) psn[o] = load16<o * 64>(pp);
+            else if constexpr (o < OT - 1) pdn[o - KS] = load16<(o - KS) * 64>(dp);
+        }, std::make_integer_sequence<int, OT>{});
+        if (RAGGED)
+            tile_ready<0>(en, psn, pdn, sn, dn);      // a wave past the end issues no stores
+        else
+            tile_ready<1>(en, psn, pdn, sn, dn);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+template <int NH, bool RAGGED>
+static int launch_ring256(const Ring256Args& a, hipStream_t st) {
+    auto kern = edge_block_ring256_kernel<NH, RAGGED>;
+    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, r256::LDS_BYTES),
+                       "hipFuncSetAttribute(edge_block_ring256)");
+    if (rc != CGNN_OK) return rc;
+    const int grid = (int)(a.steps < (int64_t)num_compute_units() ? a.steps : (int64_t)num_compute_units());
+    kern<<<grid, CGNN_R256_BLOCK, r256::LDS_BYTES, st>>>(a);
+    return check_hip(hipGetLastError(), "cgnn_edge_block(ring 256) launch");
+}
+
+// Called by cgnn_edge_block (edge_block.hip) for CGNN_BF16_N16 models with latent = hidden = 256.
+int edge_block_ring256(const MlpDev& m, const __bf16* ps, const __bf16* pd, const int32_t* src, const int32_t* dst,
+                       int64_t num_edges, const float* e_in, float* e_out, float* e_upd, int residual, hipStream_t st) {
+    if (m.nh < 1 || m.nh > 3 || !m.gamma || !m.beta) {
+        set_error("cgnn_edge_block: the 256-wide CGNN_BF16_N16 kernel needs 1..3 hidden layers and LayerNorm");
+        return CGNN_ERR_UNSUPPORTED;
+    }
+    Ring256Args a;
+    memset(&a, 0, sizeof(a));
+    for (int l = 0; l <= m.nh; ++l) {
+        a.unit[l] = reinterpret_cast<const char*>(m.w[l]);
+        a.bias[l] = m.b[l];
+        if (l >= 1 && !m.b[l]) {
+            set_error("cgnn_edge_block: the 256-wide CGNN_BF16_N16 kernel needs a bias on every Linear");
+            return CGNN_ERR_UNSUPPORTED;
+        }
+    }
+    a.gamma = m.gamma;
+    a.beta = m.beta;
+    a.ps = ps;
+    a.pd = pd;
+    a.src = src;
+    a.dst = dst;
+    a.e_in = e_in;
+    a.e_out = e_out;
+    a.e_upd = e_upd;
+    a.num_edges = num_edges;
+    a.residual = residual;
+    a.half_tiles = 2 * ((num_edges + 31) / 32);
+    const int64_t full = a.half_tiles / 8;
+    int rc = CGNN_OK;
+#define CGNN_GO(NHh, RAG) \
+    if (rc == CGNN_OK && m.nh == NHh) rc = launch_ring256<NHh, RAG>(a, st);
+    if (full > 0) {
+        a.first_half_tile = 0;
+        a.steps = full;
+        CGNN_GO(1, false) CGNN_GO(2, false) CGNN_GO(3, false)
+    }
+    if (rc == CGNN_OK && a.half_tiles % 8 != 0) {
+        a.first_half_tile = full * 8;
+        a.steps = 1;
+        CGNN_GO(1, true) CGNN_GO(2, true) CGNN_GO(3, true)
+    }
+#undef CGNN_GO
+    return rc;
+}
+
+}  // namespace cgnn

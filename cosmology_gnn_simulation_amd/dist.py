@@ -332,7 +332,7 @@ class ShardedForward:
         if not self._projected:     # first round: the owned rows too (later rounds: emitted by the node kernel)
             ops.project_nodes(p.ws, p.wd, x_own, ps_own, self.pd, p.p_format)
         edge_mode = m.message_source == "edge"
-        if edge_mode and p.edge.precision == _lib.BF16_N16 and sh.k in (8, 16):   # aggregation folded in
+        if edge_mode and p.edge.precision == _lib.BF16_N16 and sh.k in (8, 16) and self.x_all.shape[1] <= 128:   # aggregation folded in
             ops.edge_block(p.edge, self.ps, self.pd, sh.src_local, sh.dst_local, self.el, self.el, None, True,
                            agg_out=self.agg, x_gather=None, seg_k=sh.k)
         else:

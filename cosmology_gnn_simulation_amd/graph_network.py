@@ -240,9 +240,12 @@ class _PackedProcessor:
         self.wd = ops.PackedLinear(w1e, b1e, proj_precision, D, D)
         self.edge = _pack_mlp(net.edge_model, edge_precision, first_layer_cols=(2 * D, D))
         # keep_32_row_edges: the model runs its edge stream through cgnn_edge_stream_run, which takes the 32-row packing
-        if not keep_32_row_edges and self.edge.precision == _lib.BF16 and D <= 128 and self.edge.hidden <= 128 and \
-                self.edge.lds_bytes() <= _lib.LDS_WEIGHT_BUDGET:
-            # weights fit in LDS: use the 16-edge-per-wave kernel (its own packing + P-table format)
+        wide = D == 256 and self.edge.hidden == 256 and self.edge.num_hidden_layers <= 3 and \
+            all(l.bias is not None for l in _split_mlp(net.edge_model)[0])
+        if not keep_32_row_edges and self.edge.precision == _lib.BF16 and (wide or (
+                D <= 128 and self.edge.hidden <= 128 and self.edge.lds_bytes() <= _lib.LDS_WEIGHT_BUDGET)):
+            # the 16-edge-per-wave kernels (own packing + P-table format): weights resident in LDS up to 128, streamed
+            # through an LDS ring at latent = hidden = 256
             self.edge = _pack_mlp(net.edge_model, "bf16_n16", first_layer_cols=(2 * D, D))
         self.p_format = ops.p_table_format(self.edge.precision)
         self.p_dtype = ops.p_table_dtype(self.edge.precision)
@@ -275,7 +278,7 @@ def _run_round(p: _PackedProcessor, x: torch.Tensor, e: torch.Tensor, src, dst, 
         ps, pd = ops.project_nodes(p.ws, p.wd, x, ps, pd, p.p_format)
     if message_source not in ("x_j", "edge"):
         raise ValueError(f"message_source must be 'x_j' or 'edge', got {message_source!r}")
-    if message_source == "edge" and p.edge.precision == _lib.BF16_N16 and fixed_k in (8, 16):
+    if message_source == "edge" and p.edge.precision == _lib.BF16_N16 and fixed_k in (8, 16) and x.shape[1] <= 128:
         # the 16-edge kernel folds the aggregation of the edge updates in: one wave tile is exactly one (k=16) or
         # two (k=8) receivers, so the sum is a cross-lane reduction and the e_upd round trip (2 E D 4 bytes)
         # disappears.  (Folding the x_j gather in as well measured slower than the stand-alone kernel: +2.0 ms

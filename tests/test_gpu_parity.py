@@ -204,7 +204,7 @@ def test_aggregate_tiled_messages(n, k, width):
 
 
 @pytest.mark.parametrize("fmt,tol", [("fp32", 2e-6), ("bf16", 3e-2), ("bf16_n16", 3e-2)])
-@pytest.mark.parametrize("n,k,d", [(300, 8, 32), (1000, 16, 128), (70, 5, 64)])
+@pytest.mark.parametrize("n,k,d", [(300, 8, 32), (1000, 16, 128), (70, 5, 64), (1000, 32, 256), (77, 7, 256)])
 def test_edge_block_kernel_variants(fmt, tol, n, k, d):
     """Every edge-kernel variant (exact f32, 32-row bf16, 16-row bf16) against the oracle's edge update."""
     gen = torch.Generator().manual_seed(n + d)
