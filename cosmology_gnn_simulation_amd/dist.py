@@ -124,6 +124,20 @@ def build_shard(pos_global: torch.Tensor, box_size: float, k: int, world: int, r
     knn = knn_fn or (lambda p, b, kk, q: ops.knn_periodic(p, b, kk, query_ids=q, want_edge_attr=True,
                                                           want_order=True))
     t0 = time.perf_counter()
+    search_ms = 0.0
+
+    def timed_knn(p, b, kk, q):     # device time of the neighbour search alone (the torch glue around it is host-bound)
+        nonlocal search_ms
+        if dev.type != "cuda":
+            return knn(p, b, kk, q)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = knn(p, b, kk, q)
+        e1.record()
+        e1.synchronize()
+        search_ms += e0.elapsed_time(e1)
+        return out
+
     lo, hi = tile_bounds(box_size, world, rank)
     margin = margin_factor * box_size * (3.0 * k / (4.0 * 3.141592653589793 * max(n_total, 1))) ** (1.0 / 3.0)
     while True:
@@ -136,11 +150,11 @@ def build_shard(pos_global: torch.Tensor, box_size: float, k: int, world: int, r
         # a one-query pass builds the cell grid and yields the spatial (cell-sorted) order, so that the local
         # numbering is cache friendly; then the real pass over the owned queries in that order
         if owned_s.numel():
-            _, _, order = knn(pos_sub, box_size, k, owned_s[:1].to(torch.int32))
+            _, _, order = timed_knn(pos_sub, box_size, k, owned_s[:1].to(torch.int32))
             if order is not None:
                 order = order.long()
                 owned_s = order[own_sub[order] == rank]
-        senders_s, edge_attr, _ = knn(pos_sub, box_size, k, owned_s.to(torch.int32))
+        senders_s, edge_attr, _ = timed_knn(pos_sub, box_size, k, owned_s.to(torch.int32))
         if whole or owned_s.numel() == 0:
             break
         # k-th neighbour distance (minimum image) of every owned particle against the margin
@@ -154,7 +168,8 @@ def build_shard(pos_global: torch.Tensor, box_size: float, k: int, world: int, r
     senders = senders_s.long() if whole else sub[senders_s.long()]
     if dev.type == "cuda":
         torch.cuda.synchronize(dev)
-    knn_ms = (time.perf_counter() - t0) * 1e3
+    build_ms = (time.perf_counter() - t0) * 1e3          # selection of the tile + margin subset, both searches, the check
+    knn_ms = search_ms if dev.type == "cuda" else build_ms
     n_owned = owned.numel()
     senders = senders.long()
     remote = owner[senders] != rank
@@ -183,6 +198,7 @@ def build_shard(pos_global: torch.Tensor, box_size: float, k: int, world: int, r
     sh = Shard(rank, world, k, n_owned, ghosts.numel(), owned, ghosts, src_local, dst_local, edge_attr,
                recv_counts, want_global=want, knn_ms=knn_ms, n_interior=n_interior)
     sh._g2l = g2l
+    sh.subset_build_ms = build_ms
     return sh
 
 

@@ -1,0 +1,72 @@
+"""Developer tool: one rank's share of `bench.py --gpus N` on ONE GPU, without the exchange (a halo stand-in that copies
+nothing): what a rank computes per forward next to the unsharded forward of the same size.
+    python scripts/time_shard.py [--world 8] [--particles 1000000] [--scaling weak]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cosmology_gnn_simulation_amd import dist as cdist, graph_network, ops, synthetic  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--world", type=int, default=8)
+ap.add_argument("--rank", type=int, default=0)
+ap.add_argument("--particles", type=int, default=1_000_000)
+ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+ap.add_argument("--neighbors", type=int, default=16)
+ap.add_argument("--latent", type=int, default=128)
+ap.add_argument("--mp-steps", type=int, default=10)
+ap.add_argument("--iters", type=int, default=5)
+a = ap.parse_args()
+dev = torch.device("cuda")
+per = a.particles if a.scaling == "weak" else a.particles // a.world
+meta = synthetic.make_metadata()
+
+
+class NoExchange:       # the interface ShardedForward overlaps with (start / finish); ghost rows keep whatever they hold
+    def start(self, table):
+        return None
+
+    def finish(self, handle):
+        return None
+
+    def __call__(self, table):
+        return None
+
+
+t0 = time.perf_counter()
+snap = synthetic.make_snapshot(per * a.world, seed=1236)
+coords = snap["Coordinates"][:5].to(dev)
+energy = snap["InternalEnergy"][:5].to(dev)
+pos = torch.remainder(coords[-1], meta["box_size"]).contiguous()
+sh = cdist.build_shard(pos, meta["box_size"], a.neighbors, a.world, a.rank)
+sh = cdist.build_shard(pos, meta["box_size"], a.neighbors, a.world, a.rank)       # second call: allocator and kernels warm
+# every peer's request list is needed to finish the plan; without peers the send side stays empty
+cdist.finish_shard(sh, [torch.empty(0, dtype=torch.int64, device=dev) for _ in range(a.world)])
+sh.x_feat, _ = ops.window_features(coords[:, sh.owned_global].contiguous(), energy[:, sh.owned_global].contiguous(), meta,
+                                   meta["dt"], meta["box_size"])
+torch.cuda.synchronize()
+print(f"shard of rank {a.rank}/{a.world}: {sh.n_owned} owned ({sh.n_interior} interior), {sh.n_ghost} ghosts, "
+      f"k-NN searches over tile + margin {sh.knn_ms:.2f} ms (subset selection + searches + margin check "
+      f"{sh.subset_build_ms:.1f} ms), everything incl. snapshot {time.perf_counter() - t0:.1f} s", flush=True)
+d, L = a.latent, a.mp_steps
+m = graph_network.EncodeProcessDecode(d, d, 2, L, 3)
+m.load_state_dict(synthetic.make_state_dict(d, d, 2, L, 3))
+m = m.to(dev).eval()
+m.edge_precision, m.node_precision = "bf16", "fp16x2"
+run = cdist.ShardedForward(m, sh, halo=NoExchange())
+for _ in range(2):
+    run()
+torch.cuda.synchronize()
+with ops.OpTimer() as tm:
+    t1 = time.perf_counter()
+    for _ in range(a.iters):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t1) / a.iters
+print(f"forward of this rank, no exchange: {dt * 1e3:.2f} ms = {sh.n_owned * a.neighbors * L / dt / 1e9:.2f} G edge-updates/s")
+for name, (c, ms) in sorted(tm.summary().items()):
+    print(f"   {name:16s} {c // a.iters:4d} calls  {ms / a.iters:8.3f} ms per forward")
