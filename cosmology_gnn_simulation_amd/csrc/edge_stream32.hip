@@ -93,6 +93,9 @@ struct Ring32 {
         : image(img), count(cnt), wave(w), lane(l), slot(0), dma_chunk(0), dma_slot(0) {}
     __device__ __forceinline__ unsigned lds0() const { return (unsigned)(uintptr_t)(LdsWeightPtr)(cgnn_smem); }
     __device__ __forceinline__ unsigned base() const { return lds0() + (unsigned)slot * G::STRIDE; }
+    __device__ __forceinline__ unsigned base_next() const {
+        return lds0() + (unsigned)((slot + 1) & (CGNN_S32_SLOTS - 1)) * G::STRIDE;
+    }
     // LDS byte address of the vector block (bias, gamma, beta) of the chunk `ahead` steps ahead of the current one
     __device__ __forceinline__ unsigned vec_addr(int ahead) const {
         return lds0() + (unsigned)((slot + ahead) & (CGNN_S32_SLOTS - 1)) * G::STRIDE + G::VEC_OFF;
@@ -105,6 +108,8 @@ struct Ring32 {
         if (primed) return;
 #endif
         const unsigned off = (unsigned)(wave + CGNN_S32_WAVES * i) * 1024u;
+        // (a scalar-base form of the instruction -- s_mov m0 + global_load_lds with an SGPR base and one constant lane
+        // offset, no vector add per piece -- measured 0.1-0.5 ms SLOWER here: its asm statement is a scheduling fence)
         const char* src = image + (size_t)dma_chunk * G::STRIDE + off + lane * 16;
         char* dst = cgnn_smem + (unsigned)dma_slot * G::STRIDE + off;
         asm volatile("" ::: "memory");
@@ -295,6 +300,48 @@ __device__ __forceinline__ void wblock32(f32x16 (&acc)[NROW], const bf16x8 (&in)
         }, std::make_integer_sequence<int, GS>{});
     }, std::make_integer_sequence<int, NG>{});
 #undef CGNN_S32_FRAG
+}
+
+// The same block with its fragment pipeline running ACROSS block boundaries.  wblock32 starts every block by requesting
+// its first PD groups and waiting for the first of them: an LDS round trip with nothing in flight, six times per pass.
+// Here the caller owns the fragment buffers; a block finds its first PD groups already requested (by the block before
+// it, or wprefetch32 at the start of the kernel) and requests the first PD groups of the NEXT block behind its own last
+// MFMAs -- the next block reads either the same chunk (the other tile) or the next one, which the step's barrier has
+// already confirmed.  One fragment read behind every MFMA, always; every wait leaves (PD - 1) groups in flight.
+// Group p of a block lives in buf[p % (PD + 1)]: the next block's group g + PD - NG lands in the slot group g has just
+// been read from, which is the right one when (NG - PD) is a multiple of PD + 1 (32 / 4 = 8 groups and the encoder's 2).
+typedef u32x4 WBuf32[CGNN_S32_PD + 1][4];
+__device__ __forceinline__ void wprefetch32(WBuf32& buf, unsigned addr) {
+    const unsigned a = addr + (unsigned)(threadIdx.x & 63) * 16u;
+    static_for_each([&](auto pc) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc)::value;
+        static_for_each([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            buf[p][j] = lds_read_b128_acc<(p * 4 + j) * 1024>(a);
+        }, std::make_integer_sequence<int, 4>{});
+    }, std::make_integer_sequence<int, CGNN_S32_PD>{});
+}
+template <int NROW, int KS, class Fill>
+__device__ __forceinline__ void wblock32p(f32x16 (&acc)[NROW], const bf16x8 (&in)[KS], unsigned addr, unsigned next_addr,
+                                          WBuf32& buf, const Fill& fill) {
+    constexpr int M = NROW * KS, GS = 4, NG = M / GS, PD = CGNN_S32_PD, NBUF = PD + 1;
+    static_assert(M % GS == 0 && NG >= PD && (NG - PD) % NBUF == 0, "block shape does not close the buffer rotation");
+    const unsigned a = addr + (unsigned)(threadIdx.x & 63) * 16u, an = next_addr + (unsigned)(threadIdx.x & 63) * 16u;
+    static_for_each([&](auto gc) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value;
+        lds_wait4i<(PD - 1) * GS>(buf[g % NBUF][0], buf[g % NBUF][1], buf[g % NBUF][2], buf[g % NBUF][3]);
+        static_for_each([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value, m = g * GS + j, o = m / KS, ks = m % KS;
+            acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, buf[g % NBUF][j]), in[ks], acc[o], 0, 0,
+                                                             0);
+            if constexpr (g + PD < NG)
+                buf[(g + PD) % NBUF][j] = lds_read_b128_acc<((g + PD) * GS + j) * 1024>(a);
+            else
+                buf[(g + PD - NG) % NBUF][j] = lds_read_b128_acc<((g + PD - NG) * GS + j) * 1024>(an);
+            fill.template run<m>();
+            __builtin_amdgcn_sched_barrier(0);
+        }, std::make_integer_sequence<int, GS>{});
+    }, std::make_integer_sequence<int, NG>{});
 }
 
 // P rows (CGNN_P_BF16_S32: lane (r, h) owns the 16-byte pieces 2 t + s of its half of the row = the B operand of k-step
@@ -620,6 +667,19 @@ __global__ __launch_bounds__(CGNN_S32_BLOCK, 1) void edge_stream32_kernel(
     if (iters == 0) return;
     Ring32<G> ring(a.image, steps_per_pair, wave, lane);
     ring.prime();
+    // latent 128: the LDS fragment pipeline runs across block boundaries (wblock32p); its buffers live here
+#ifdef CGNN_S32_NO_XBLOCK     // developer A/B: every block starts its own fragment pipeline
+    constexpr bool XBLOCK = false;
+#else
+    constexpr bool XBLOCK = DT == 4;
+#endif
+    WBuf32 wbuf;
+    if constexpr (XBLOCK) wprefetch32(wbuf, ring.base());
+#define CGNN_S32_WB(KSx, ACC, IN, BASE, NEXT, ...)                                  \
+    if constexpr (XBLOCK)                                                           \
+        wblock32p<DT, KSx>(ACC, IN, BASE, NEXT, wbuf, __VA_ARGS__);                 \
+    else                                                                            \
+        wblock32<DT, KSx>(ACC, IN, BASE, __VA_ARGS__)
     const bf16x8 sel0 = p32_selector(lane, 0), sel1 = p32_selector(lane, 1);
 
     Tile32<DT> A, B;
@@ -725,7 +785,7 @@ __global__ __launch_bounds__(CGNN_S32_BLOCK, 1) void edge_stream32_kernel(
                 if constexpr (IS_ENC) {
                     bias_rows32<DT, 0, DT>(A.acc, ring.vec_addr(0), h);
                     const bf16x8 (&inA)[2] = reinterpret_cast<const bf16x8(&)[2]>(A.in[0]);
-                    wblock32<DT, 2>(A.acc, inA, base, make_fill([&](auto qc) __attribute__((always_inline)) {
+                    CGNN_S32_WB(2, A.acc, inA, base, base, make_fill([&](auto qc) __attribute__((always_inline)) {
                         constexpr int q = decltype(qc)::value;
                         if constexpr (q == MQ0 - 1) bias_rows32<DT, 0, DT>(B.acc, ring.vec_addr(0), h);
                     }));
@@ -749,7 +809,7 @@ __global__ __launch_bounds__(CGNN_S32_BLOCK, 1) void edge_stream32_kernel(
                         if constexpr ((q & 3) == 3) p_issue_range(tps, tpd, soB, doB, CGNN_IC(q - 3), CGNN_IC(q + 1));
                     }));
                     CGNN_S32_STAMP(1);
-                    wblock32<DT, KS>(A.acc, A.in, base, make_fill([&](auto qc) __attribute__((always_inline)) {
+                    CGNN_S32_WB(KS, A.acc, A.in, base, base, make_fill([&](auto qc) __attribute__((always_inline)) {
                         constexpr int q = decltype(qc)::value;
                         if constexpr (PEND != 0) {
                             constexpr int lo = S1 + share_lo(NLN - S1, MQ, q), hi = S1 + share_hi(NLN - S1, MQ, q);
@@ -763,7 +823,7 @@ __global__ __launch_bounds__(CGNN_S32_BLOCK, 1) void edge_stream32_kernel(
                 CGNN_S32_STAMP(3);
                 if constexpr (IS_ENC) {
                     const bf16x8 (&inB)[2] = reinterpret_cast<const bf16x8(&)[2]>(B.in[0]);
-                    wblock32<DT, 2>(B.acc, inB, base, make_fill([&](auto qc) __attribute__((always_inline)) {
+                    CGNN_S32_WB(2, B.acc, inB, base, ring.base_next(), make_fill([&](auto qc) __attribute__((always_inline)) {
                         constexpr int q = decltype(qc)::value;
                         pack32_run<true, DT, share_lo(NPACK, MQ0, q), share_hi(NPACK, MQ0, q)>(A);
                         for (int i = share_lo(G::NP, MQ0, q); i < share_hi(G::NP, MQ0, q); ++i) ring.piece(i);
@@ -779,7 +839,7 @@ __global__ __launch_bounds__(CGNN_S32_BLOCK, 1) void edge_stream32_kernel(
                         for (int i = share_lo(G::NP, PQ, q); i < share_hi(G::NP, PQ, q); ++i) ring.piece(i);
                     }));
                     CGNN_S32_STAMP(5);
-                    wblock32<DT, KS>(B.acc, B.in, base, make_fill([&](auto qc) __attribute__((always_inline)) {
+                    CGNN_S32_WB(KS, B.acc, B.in, base, ring.base_next(), make_fill([&](auto qc) __attribute__((always_inline)) {
                         constexpr int q = decltype(qc)::value;
                         if constexpr (q < QP) pack32_run<true, DT, share_lo(NPACK, QP, q), share_hi(NPACK, QP, q)>(A);
                         if constexpr (q == QB) bias_rows32<DT, 0, DT>(A.acc, ring.vec_addr(1), h);
@@ -793,7 +853,7 @@ __global__ __launch_bounds__(CGNN_S32_BLOCK, 1) void edge_stream32_kernel(
             // ---------------- hidden layers 1 .. nh - 1 ----------------
             for (int l = 1; l < nh; ++l) {
                 const unsigned base = ring.base();
-                wblock32<DT, KS>(A.acc, A.in, base, make_fill([&](auto qc) __attribute__((always_inline)) {
+                CGNN_S32_WB(KS, A.acc, A.in, base, base, make_fill([&](auto qc) __attribute__((always_inline)) {
                     constexpr int q = decltype(qc)::value;
                     if constexpr (q < QP) pack32_run<true, DT, share_lo(NPACK, QP, q), share_hi(NPACK, QP, q)>(B);
                     if constexpr (q == QB) bias_rows32<DT, 0, DT>(B.acc, ring.vec_addr(0), h);
@@ -801,7 +861,7 @@ __global__ __launch_bounds__(CGNN_S32_BLOCK, 1) void edge_stream32_kernel(
                 CGNN_S32_STAMP(7);
                 ring.template sync_next<0>();
                 CGNN_S32_STAMP(8);
-                wblock32<DT, KS>(B.acc, B.in, base, make_fill([&](auto qc) __attribute__((always_inline)) {
+                CGNN_S32_WB(KS, B.acc, B.in, base, ring.base_next(), make_fill([&](auto qc) __attribute__((always_inline)) {
                     constexpr int q = decltype(qc)::value;
                     for (int i = share_lo(G::NP, MQ, q); i < share_hi(G::NP, MQ, q); ++i) ring.piece(i);
                     if constexpr (q < QP) pack32_run<true, DT, share_lo(NPACK, QP, q), share_hi(NPACK, QP, q)>(A);
@@ -821,7 +881,7 @@ __global__ __launch_bounds__(CGNN_S32_BLOCK, 1) void edge_stream32_kernel(
                 const bool wrap = !IS_ENC && rr + 1 == L;
                 const __bf16* nps = (IS_ENC || wrap) ? ps_all : tps + round_stride;
                 const __bf16* npd = (IS_ENC || wrap) ? pd_all : tpd + round_stride;
-                wblock32<DT, KS>(A.acc, A.in, base, make_fill([&](auto qc) __attribute__((always_inline)) {
+                CGNN_S32_WB(KS, A.acc, A.in, base, base, make_fill([&](auto qc) __attribute__((always_inline)) {
                     constexpr int q = decltype(qc)::value;
                     if constexpr (q < QP) pack32_run<true, DT, share_lo(NPACK, QP, q), share_hi(NPACK, QP, q)>(B);
                     p_issue_range(nps, npd, soA, doA, CGNN_IC(share_lo(NPL, MQ, q)), CGNN_IC(share_hi(NPL, MQ, q)));
@@ -831,7 +891,7 @@ __global__ __launch_bounds__(CGNN_S32_BLOCK, 1) void edge_stream32_kernel(
                 ring.template sync_next<NPL>();
                 CGNN_S32_STAMP(11);
                 // pieces in the first slots, A's LayerNorm over all of them
-                wblock32<DT, KS>(B.acc, B.in, base, make_fill([&](auto qc) __attribute__((always_inline)) {
+                CGNN_S32_WB(KS, B.acc, B.in, base, ring.base_next(), make_fill([&](auto qc) __attribute__((always_inline)) {
                     constexpr int q = decltype(qc)::value;
                     constexpr int qp = prev_share_slot(NLN, MQ, q);
                     ln32_run<!IS_ENC, DT, share_lo(NLN, MQ, q), share_hi(NLN, MQ, q), (qp < 0 ? 0 : WB::frags_between(qp, q))>(
@@ -879,6 +939,7 @@ __global__ __launch_bounds__(CGNN_S32_BLOCK, 1) void edge_stream32_kernel(
     CGNN_S32_VMCNT(0);      // the ring's last refills (unread) must have landed before the workgroup's LDS is released
     __builtin_amdgcn_s_barrier();
 #undef CGNN_IC
+#undef CGNN_S32_WB
 }
 
 template <int DT>
