@@ -16,8 +16,8 @@
 // stores, projections) of the current one and are the only other loads, waited for once per step with a count that
 // leaves the step's stores in flight.  All vector-memory loads are inline asm so that the compiler inserts no waits of
 // its own; vector-memory operations retire in order, so each counted wait names exactly the operations issued after
-// the one it needs (a smaller count is always safe, a larger one never is: the launcher only sends full steps here --
-// every store is issued by every wave -- and the <128 remaining rows go to the two-slot kernel).
+// the one it needs (a smaller count is always safe, a larger one never is: in a full step every wave issues every store;
+// the one step that may be partial -- the last -- drains instead).
 #include <string.h>
 
 #include "f2_ring.hpp"
@@ -41,7 +41,8 @@ struct F2RingArgs {
     float* x_out;
     __bf16* ps_next;
     __bf16* pd_next;
-    int64_t steps;                           // 128-row steps
+    int64_t n;                               // rows
+    int64_t steps;                           // 128-row steps, the last one may be partial
     int32_t residual;
 };
 
@@ -104,7 +105,8 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
     int64_t step = blockIdx.x;
     f32x4 xn[OT], an[OT];
     {
-        const int64_t row = (step * WAVES + wave) * 16 + c;
+        const int64_t row0 = (step * WAVES + wave) * 16 + c;
+        const int64_t row = row0 < a.n ? row0 : a.n - 1;
         const float* xp = a.x + row * D + 4 * q;
         const float* ap = a.agg + row * D + 4 * q;
         static_for_each([&](auto oc) { xn[decltype(oc)::value] = row_load<decltype(oc)::value * 64>(xp); },
@@ -120,8 +122,12 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
 #ifdef CGNN_F2R_ABL_XLOAD
         const int64_t next_row = (blockIdx.x * WAVES + wave) * 16 + c + 0 * next_step;
 #else
-        const int64_t next_row = (next_step * WAVES + wave) * 16 + c;
+        const int64_t next_row0 = (next_step * WAVES + wave) * 16 + c;
+        const int64_t next_row = next_row0 < a.n ? next_row0 : a.n - 1;      // rows past the end: the last row again
 #endif
+        // the last step may hold fewer than 128 rows: loads are clamped, stores predicated, and its closing wait
+        // drains everything (a wave without live rows issues no stores for the counted wait to lean on)
+        const bool partial = step == a.steps - 1 && (a.n & 127) != 0;
 
 #ifdef CGNN_F2R_STAMPS
         const bool stamp_on = blockIdx.x == 9 && step == blockIdx.x + 3 * (int64_t)nb;
@@ -186,6 +192,7 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
         F2R_STAMP(9);
         char* const stage = cgnn_smem + RING_OFF + (slot == 0 ? NS - 1 : slot - 1) * CHUNK + wave * 2048;
         const int64_t tile_row = (step * WAVES + wave) * 16;
+        const bool ok0 = tile_row + (lane >> 3) < a.n, ok1 = tile_row + (lane >> 3) + 8 < a.n;    // rows of the staged stores
         fold16f2<OT>(c0, c1);
 #ifndef CGNN_F2R_ABL_LN
         layer_norm16<OT>(c0, vec + (NH + 1) * D, vec + (NH + 2) * D, q);
@@ -207,8 +214,8 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
 #ifdef CGNN_F2R_ABL_XSTORE
                 asm volatile("" ::"v"(v0), "v"(v1), "v"(xo));
 #else
-                *reinterpret_cast<f32x4*>(xo + p * 32) = v0;
-                *reinterpret_cast<f32x4*>(xo + p * 32 + 8 * D) = v1;
+                if (ok0) *reinterpret_cast<f32x4*>(xo + p * 32) = v0;
+                if (ok1) *reinterpret_cast<f32x4*>(xo + p * 32 + 8 * D) = v1;
 #endif
             }
         }
@@ -242,11 +249,11 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
                     }
                     const LdsU4Ptr r = (LdsU4Ptr)(stage + lane * 16);
                     const u32x4 v0 = r[0], v1 = r[64];
-                    *reinterpret_cast<u32x4*>(pt + pp * 64) = v0;
-                    *reinterpret_cast<u32x4*>(pt + pp * 64 + 8 * D * 2) = v1;
+                    if (ok0) *reinterpret_cast<u32x4*>(pt + pp * 64) = v0;
+                    if (ok1) *reinterpret_cast<u32x4*>(pt + pp * 64 + 8 * D * 2) = v1;
                 }
             } else {
-                store_p16<PFMT, OT>(acc, base, row, q);
+                if (row < a.n) store_p16<PFMT, OT>(acc, base, row, q);
             }
         };
         if (proj) {   // block-uniform
@@ -271,7 +278,10 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
 #if defined(CGNN_F2R_ABL_PSTORE) || defined(CGNN_F2R_ABL_XSTORE)
         rows_ready<0>(xn, an);
 #else
-        rows_ready<8>(xn, an);
+        if (partial)
+            rows_ready<0>(xn, an);
+        else
+            rows_ready<8>(xn, an);
 #endif
         F2R_STAMP(13);
     }
@@ -311,14 +321,14 @@ static int launch_f2ring(const F2RingArgs& a, hipStream_t st) {
     return check_hip(hipGetLastError(), "cgnn_node_block(f16x2 ring) launch");
 }
 
-// The first 128 * steps rows of a CGNN_F16X2_N16 node block with latent = hidden = 128 and nh <= 3 hidden layers.
-// Returns CGNN_OK and the number of rows done in *rows_done (0: shape not covered, nothing launched).
+// A CGNN_F16X2_N16 node block with latent = hidden = 128 and nh <= 3 hidden layers.  Returns CGNN_OK and the number of
+// rows done in *rows_done (n, or 0: shape not covered, nothing launched).
 int node_block_f2ring(const MlpDev& m, const cgnn_linear* w_x, const cgnn_linear* w_agg, const float* x, const float* agg,
                       int64_t n, float* x_out, int residual, bool fuse, const cgnn_linear* ws_next,
                       const cgnn_linear* wd_next, void* ps_next, void* pd_next, int p_format, hipStream_t st,
                       int64_t* rows_done) {
     *rows_done = 0;
-    const int64_t steps = n / 128;
+    const int64_t steps = (n + 127) / 128;
     if (m.nh < 1 || m.nh > 3 || steps == 0 || !m.gamma || !m.beta) return CGNN_OK;
     F2RingArgs a;
     memset(&a, 0, sizeof(a));
@@ -342,6 +352,7 @@ int node_block_f2ring(const MlpDev& m, const cgnn_linear* w_x, const cgnn_linear
     a.x_out = x_out;
     a.ps_next = fuse ? (__bf16*)ps_next : nullptr;
     a.pd_next = fuse ? (__bf16*)pd_next : nullptr;
+    a.n = n;
     a.steps = steps;
     a.residual = residual;
     const bool s16 = fuse && p_format == CGNN_P_BF16_S16;
@@ -351,7 +362,7 @@ int node_block_f2ring(const MlpDev& m, const cgnn_linear* w_x, const cgnn_linear
         rc = s16 ? launch_f2ring<NHh, CGNN_P_BF16_S16>(a, st) : launch_f2ring<NHh, CGNN_P_BF16_S32>(a, st);
     CGNN_GO(1) CGNN_GO(2) CGNN_GO(3)
 #undef CGNN_GO
-    if (rc == CGNN_OK) *rows_done = steps * 128;
+    if (rc == CGNN_OK) *rows_done = n;
     return rc;
 }
 

@@ -285,7 +285,8 @@ int node_block_x3n16(const MlpDev& m, int precision, const cgnn_linear* w_x, con
                      hipStream_t st) {
     const bool f2 = precision == CGNN_F16X2_N16;
     if (f2 && T == 4) {
-        // whole 128-row steps go to the five-slot-ring kernel (node_block_f2.hip), the rest (< 128 rows) to the kernel below
+        // the five-slot-ring kernel (node_block_f2.hip) takes every row when it covers the shape (1..3 hidden layers,
+        // LayerNorm, a bias on every Linear); otherwise (done == 0) the two-slot kernel below runs
         int64_t done = 0;
         int rc = node_block_f2ring(m, w_x, w_agg, x, agg, n, x_out, residual, fuse, ws_next, wd_next, ps_next, pd_next,
                                    p_format, st, &done);
