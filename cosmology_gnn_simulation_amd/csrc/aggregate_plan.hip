@@ -6,7 +6,7 @@
 //
 // cgnn_aggregate's fixed-k kernel reads k rows per receiver from L2: 16 M row gathers (8.2 GB) per round at cfg3, 13.7
 // TB/s of L2 -> CU traffic and 0.60 ms, although the receivers are in spatial (cell) order and neighbouring receivers
-// share most of their senders.  The plan cuts the receivers into blocks of 64 consecutive ones and stores, per block,
+// share most of their senders.  The plan cuts the receivers into blocks of 64 (k = 8, 16; else 32) consecutive ones and stores, per block,
 // the list of DISTINCT sender rows (about 300 of the 1024 references at k = 16 on a uniform box) and, per edge, the
 // position of its sender in that list (uint16).  The kernel copies a block's distinct rows into LDS once (a 32-feature
 // slice at a time: up to 352 rows x 128 B) and every receiver sums its k neighbours from LDS, in the same order as
@@ -20,7 +20,9 @@
 
 namespace cgnn {
 
-#define CGNN_AP_BLOCK_ROWS 64          // receivers per block
+// receivers per block: 64 for the unrolled k = 8 / 16 kernels (two receivers per thread), 32 for the runtime-k kernel
+// (one per thread; up to k = 32 a block's distinct senders then still fit the staging area)
+__host__ __device__ inline int ap_block_rows(int k) { return (k == 8 || k == 16) ? 64 : 32; }
 #define CGNN_AP_MAX_UNIQUE 512         // distinct senders a block's list can hold
 #define CGNN_AP_STAGE_ROWS 352         // ... of which the kernel stages this many (two slices of them in flight in registers: 2 workgroups per CU); more: direct gather
 #define CGNN_AP_ROW_F4 9               // LDS row pitch in 16-byte units: 128 bytes of data + 16 of padding
@@ -53,8 +55,9 @@ __global__ __launch_bounds__(CGNN_AP_THREADS) void aggregate_plan_kernel(const i
     __shared__ int32_t rank[CGNN_AP_HASH];
     __shared__ int32_t wave_total[CGNN_AP_THREADS / 64];
     const int64_t b = blockIdx.x;
-    const int64_t row0 = b * CGNN_AP_BLOCK_ROWS;
-    const int rows = (int)((num_nodes - row0) < CGNN_AP_BLOCK_ROWS ? (num_nodes - row0) : CGNN_AP_BLOCK_ROWS);
+    const int block_rows = ap_block_rows(k);
+    const int64_t row0 = b * block_rows;
+    const int rows = (int)((num_nodes - row0) < block_rows ? (num_nodes - row0) : block_rows);
     const int refs = rows * k;
     const int32_t* g = gather + row0 * k;
     for (int i = threadIdx.x; i < CGNN_AP_HASH; i += CGNN_AP_THREADS) keys[i] = -1;
@@ -124,7 +127,8 @@ __global__ __launch_bounds__(CGNN_AP_THREADS) void aggregate_planned_kernel(cons
     const int64_t nblk = gridDim.x, per = nblk >> 3, rem = nblk & 7;
     const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int64_t b = xcd * per + (xcd < rem ? xcd : rem) + slot;
-    const int64_t row0 = b * CGNN_AP_BLOCK_ROWS;
+    constexpr int HALVES = (K == 8 || K == 16) ? 2 : 1;     // 64-receiver blocks: two receivers per thread; else one
+    const int64_t row0 = b * (32 * HALVES);
     const int U = plan.count[b];
     const int chunk = threadIdx.x & 7;            // 16-byte piece of the 128-byte slice
     const int r_lo = threadIdx.x >> 3;            // receivers r_lo and r_lo + 32 of the block
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(CGNN_AP_THREADS) void aggregate_planned_kernel(cons
     if (U < 0 || U > CGNN_AP_STAGE_ROWS) {   // too many distinct senders: the plain gather (same summation order)
         for (int s = 0; s < slices; ++s)
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
+            for (int half = 0; half < HALVES; ++half) {
                 const int64_t row = row0 + r_lo + 32 * half;
                 if (row >= num_nodes) continue;
                 const int32_t* g = gather + row * k;
@@ -154,9 +158,9 @@ __global__ __launch_bounds__(CGNN_AP_THREADS) void aggregate_planned_kernel(cons
     }
     // positions of this thread's two receivers' senders in the block's list (read once, used for every slice)
     constexpr int KR = K ? K : CGNN_AP_MAX_K;
-    uint16_t li[2][KR];
+    uint16_t li[HALVES][KR];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < HALVES; ++half) {
         const int64_t row = row0 + r_lo + 32 * half;
         const uint16_t* lp = plan.local + (row < num_nodes ? row : num_nodes - 1) * k;
         if (K) {
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(CGNN_AP_THREADS) void aggregate_planned_kernel(cons
                 if (mine[i] >= 0) pre[P][i] = *reinterpret_cast<const f32x4*>(tcol + (int64_t)mine[i] * width + (s + 2) * 32);
         }
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < HALVES; ++half) {
             const int64_t row = row0 + r_lo + 32 * half;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             if (K == 8 || K == 16) {
@@ -239,7 +243,7 @@ extern "C" {
 
 size_t cgnn_aggregate_plan_bytes(int64_t num_nodes, int32_t fixed_k) {
     if (num_nodes <= 0 || fixed_k <= 0 || fixed_k > CGNN_AP_MAX_K) return 0;
-    const int64_t nblocks = (num_nodes + CGNN_AP_BLOCK_ROWS - 1) / CGNN_AP_BLOCK_ROWS;
+    const int64_t nblocks = (num_nodes + ap_block_rows(fixed_k) - 1) / ap_block_rows(fixed_k);
     return plan_count_bytes(nblocks) + (size_t)nblocks * CGNN_AP_MAX_UNIQUE * 4 + (size_t)num_nodes * fixed_k * 2;
 }
 
@@ -252,7 +256,7 @@ int cgnn_aggregate_plan_build(const int32_t* gather, int64_t num_nodes, int32_t 
         set_error("cgnn_aggregate_plan_build: fixed_k=%d above %d", fixed_k, CGNN_AP_MAX_K);
         return CGNN_ERR_UNSUPPORTED;
     }
-    const int64_t nblocks = (num_nodes + CGNN_AP_BLOCK_ROWS - 1) / CGNN_AP_BLOCK_ROWS;
+    const int64_t nblocks = (num_nodes + ap_block_rows(fixed_k) - 1) / ap_block_rows(fixed_k);
     aggregate_plan_kernel<<<(unsigned)nblocks, CGNN_AP_THREADS, 0, (hipStream_t)stream>>>(gather, num_nodes, fixed_k,
                                                                                          plan_view(plan, nblocks));
     return check_hip(hipGetLastError(), "cgnn_aggregate_plan_build launch");
@@ -270,7 +274,7 @@ int cgnn_aggregate_planned(const float* table, const int32_t* gather, const void
         return CGNN_ERR_UNSUPPORTED;
     }
     if (num_nodes == 0) return CGNN_OK;
-    const int64_t nblocks = (num_nodes + CGNN_AP_BLOCK_ROWS - 1) / CGNN_AP_BLOCK_ROWS;
+    const int64_t nblocks = (num_nodes + ap_block_rows(fixed_k) - 1) / ap_block_rows(fixed_k);
     const PlanView pv = plan_view(const_cast<void*>(plan), nblocks);
     const int lds = CGNN_AP_STAGE_ROWS * CGNN_AP_ROW_F4 * 16;
     hipStream_t st = (hipStream_t)stream;

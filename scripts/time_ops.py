@@ -97,9 +97,10 @@ t("aggregate x_j", lambda: ops.aggregate(x, src, dst, n, fk, E, agg), E * d * 4 
 if ops.AggregatePlan.supported(n, fk, d) and (not a.only or a.only.startswith("aggregate")):
     t("aggregate_plan", lambda: ops.AggregatePlan(src, n, fk))
     plan_ = ops.AggregatePlan(src, n, fk)
-    cnt_ = plan_.blob[: 4 * ((n + 63) // 64)].view(torch.int32).float()
-    print(f"   (plan: {float(cnt_.clamp(min=0).mean()):.0f} distinct rows per block of 64 receivers x k = {64 * fk} references, "
-          f"{int((cnt_ < 0).sum())} blocks over the limit)")
+    rows_ = 64 if fk in (8, 16) else 32
+    cnt_ = plan_.blob[: 4 * ((n + rows_ - 1) // rows_)].view(torch.int32).float()
+    print(f"   (plan: {float(cnt_.clamp(min=0).mean()):.0f} distinct rows per block of {rows_} receivers x k = {rows_ * fk} references, "
+          f"{int(((cnt_ < 0) | (cnt_ > 352)).sum())} of {cnt_.numel()} blocks gather directly)")
     t("aggregate planned", lambda: ops.aggregate(x, src, dst, n, fk, E, agg, plan=plan_), E * d * 4 + E * 4 + n * d * 4)
 # general scatter-add (fixed_k = 0): receiver-sorted list (one atomic row per receiver) and a shuffled one (one per edge);
 # GB/s = table rows read + atomic bytes added

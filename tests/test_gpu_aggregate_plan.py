@@ -30,9 +30,11 @@ def test_planned_aggregation_is_bit_identical_on_spatial_graphs(n, k, width):
     plan = ops.AggregatePlan(src, n, k)
     got = ops.aggregate(x, src, None, n, k, plan=plan)
     assert torch.equal(got, plain)
-    counts = plan.blob[: 4 * ((n + 63) // 64)].view(torch.int32)
-    assert int((counts > 0).sum()) == counts.numel()                   # every block was staged (none overflowed) ...
-    assert float(counts.float().mean()) < 0.6 * 64 * k                 # ... and holds far fewer rows than references
+    rows = 64 if k in (8, 16) else 32                                  # receivers per block
+    counts = plan.blob[: 4 * ((n + rows - 1) // rows)].view(torch.int32)
+    assert int((counts > 0).sum()) == counts.numel()                   # no block exceeds the list ...
+    assert float((counts <= 352).float().mean()) > 0.9                 # ... nearly all are staged in LDS ...
+    assert float(counts.float().mean()) < 0.6 * rows * k               # ... and hold far fewer rows than references
     dst = torch.arange(n).repeat_interleave(k)
     want = cpu_ref.propagate_add(x.cpu(), torch.stack([src.cpu().long(), dst]))
     assert float((got.cpu() - want).abs().max()) <= 1e-5 * float(want.abs().max())
@@ -45,8 +47,9 @@ def test_blocks_with_too_many_distinct_senders_take_the_direct_path(k):
     src = torch.randint(0, n, (n * k,), generator=gen).int().to(DEV)     # 64 k references per block, almost all distinct
     x = torch.randn(n, width, device=DEV)
     plan = ops.AggregatePlan(src, n, k)
-    counts = plan.blob[: 4 * ((n + 63) // 64)].view(torch.int32)
-    assert int(((counts < 0) | (counts > 352)).sum()) > 0
+    rows = 64 if k in (8, 16) else 32
+    counts = plan.blob[: 4 * ((n + rows - 1) // rows)].view(torch.int32)
+    assert int(((counts < 0) | (counts > 352)).sum()) > 0 or rows * k <= 352
     assert torch.equal(ops.aggregate(x, src, None, n, k, plan=plan), ops.aggregate(x, src, None, n, k))
 
 
