@@ -28,7 +28,9 @@ __device__ __forceinline__ void zero_tiles(f32x16 (&a)[T]) {
 }
 
 // K1T / K2T: 32-feature tiles of the two input parts (K2T = 0: single input); HT hidden tiles; OT output tiles.
-template <int K1T, int K2T, int HT, int OT, bool LN>
+// PREC: CGNN_F32 (v_mfma_f32_32x32x2_f32, exact) or CGNN_F32X3 (f32 emulated by three bf16 terms, six bf16 MFMAs per
+// product block, f32-level error: the activations and gradients stay f32 tiles, only the MFMA operands are split).
+template <int PREC, int K1T, int K2T, int HT, int OT, bool LN>
 __global__ __launch_bounds__(CGNN_BLOCK) void mlp_backward_kernel(
     MlpDev f, MlpDev b, const void* f_w2, const void* b_w2, const float* __restrict__ u1, int ld1,
     const float* __restrict__ u2, int ld2, const float* __restrict__ dy, int ld_dy, int64_t n, BwdBufs buf,
@@ -39,45 +41,56 @@ __global__ __launch_bounds__(CGNN_BLOCK) void mlp_backward_kernel(
     constexpr int K2 = K2T > 0 ? K2T : 1;
     const int in1 = f.in_dim[0], out_dim = f.out_dim[f.nh];
     const bool in1_full = (in1 == 32 * K1T) && (ld1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(u1) & 15) == 0);
-    const BufW<CGNN_F32> fw2(f_w2, K2 * HT * 4096u), bw2(b_w2, K2 * HT * 4096u);
+    constexpr unsigned TILE_BYTES = PREC == CGNN_F32X3 ? 6144u : 4096u;      // one packed 32 x 32 weight tile
+    const BufW<PREC> fw2(f_w2, K2 * HT * TILE_BYTES), bw2(b_w2, K2 * HT * TILE_BYTES);
     const TileRange tr = tile_range(tiles);
     for (int64_t tile = tr.first; tile < tr.end; tile += tr.stride) {
         const int64_t row = tile * 32 + r;
         const bool live = row < n;
         const int64_t rowc = live ? row : n - 1;
         // ------------------------------------------------------------ forward, recomputed
-        Operand<CGNN_F32, HT> oph;
+        Operand<PREC, HT> oph;
+        auto relu_store = [&](f32x16 (&acc)[HT], float* dst) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][i] = fmaxf(acc[t][i], 0.f);
+            if (live) store_rows_full<HT>(acc, dst + row * H, h);
+            oph.template from_acc<false>(acc);
+        };
         {
             f32x16 acc[HT];
             acc_fill_bias<HT>(acc, f.b[0], H, h);
             {
-                Operand<CGNN_F32, K1T> op;
+                f32x16 t1[K1T];
                 if (in1_full)
-                    load_rows_full<K1T>(op.v, u1 + rowc * ld1, h);
+                    load_rows_full<K1T>(t1, u1 + rowc * ld1, h);
                 else
-                    load_rows_ragged<K1T>(op.v, u1 + rowc * ld1, in1, h);
-                dense<K1T, HT>(acc, op, WSel<CGNN_F32, false>::get(f, 0), lane);
+                    load_rows_ragged<K1T>(t1, u1 + rowc * ld1, in1, h);
+                Operand<PREC, K1T> op;
+                op.template from_acc<false>(t1);
+                dense<K1T, HT>(acc, op, WSel<PREC, false>::get(f, 0), lane);
             }
             if (K2T > 0) {
-                Operand<CGNN_F32, K2> op;
-                load_rows_full<K2>(op.v, u2 + rowc * ld2, h);
+                f32x16 t2[K2];
+                load_rows_full<K2>(t2, u2 + rowc * ld2, h);
+                Operand<PREC, K2> op;
+                op.template from_acc<false>(t2);
                 dense<K2, HT>(acc, op, fw2, lane);
             }
-            oph.template from_acc<true>(acc);
-            if (live) store_rows_full<HT>(oph.v, buf.h[0] + row * H, h);
+            relu_store(acc, buf.h[0]);
         }
         for (int l = 1; l < f.nh; ++l) {
             f32x16 acc[HT];
             acc_fill_bias<HT>(acc, f.b[l], H, h);
-            dense<HT, HT>(acc, oph, WSel<CGNN_F32, false>::get(f, l), lane);
-            oph.template from_acc<true>(acc);
-            if (live) store_rows_full<HT>(oph.v, buf.h[l] + row * H, h);
+            dense<HT, HT>(acc, oph, WSel<PREC, false>::get(f, l), lane);
+            relu_store(acc, buf.h[l]);
         }
         f32x16 g[OT];      // becomes dL/d(pre-LayerNorm output)
         {
             f32x16 out[OT];
             acc_fill_bias<OT>(out, f.b[f.nh], out_dim, h);
-            dense<HT, OT>(out, oph, WSel<CGNN_F32, false>::get(f, f.nh), lane);
+            dense<HT, OT>(out, oph, WSel<PREC, false>::get(f, f.nh), lane);
             // -------------------------------------------------------- output gradient through LayerNorm
             if (out_dim == OW && ld_dy % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0)
                 load_rows_full<OT>(g, dy + rowc * ld_dy, h);
@@ -131,38 +144,37 @@ __global__ __launch_bounds__(CGNN_BLOCK) void mlp_backward_kernel(
         }
         if (live) store_rows_full<OT>(g, buf.g_o + row * OW, h);
         // ------------------------------------------------------------ backward through the hidden layers
-        Operand<CGNN_F32, HT> og;     // dL/d(pre-activation) of the layer being left
-        {
-            Operand<CGNN_F32, OT> go;
-            go.template from_acc<false>(g);
-            f32x16 gh[HT];
-            zero_tiles<HT>(gh);
-            dense<OT, HT>(gh, go, WSel<CGNN_F32, false>::get(b, f.nh), lane);     // W_nh^T
+        Operand<PREC, HT> og;     // dL/d(pre-activation) of the layer being left
+        // gh = W^T g of the layer above; mask by the (stored) activation's sign, keep as g_a[l], make it the next operand
+        auto relu_backward = [&](f32x16 (&gh)[HT], int l) __attribute__((always_inline)) {
             f32x16 hv[HT];
-            load_rows_full<HT>(hv, buf.h[f.nh - 1] + rowc * H, h);
+            load_rows_full<HT>(hv, buf.h[l] + rowc * H, h);
 #pragma unroll
             for (int t = 0; t < HT; ++t)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) og.v[t][i] = hv[t][i] > 0.f ? gh[t][i] : 0.f;
-            if (live) store_rows_full<HT>(og.v, buf.g_a[f.nh - 1] + row * H, h);
+                for (int i = 0; i < 16; ++i) gh[t][i] = hv[t][i] > 0.f ? gh[t][i] : 0.f;
+            if (live) store_rows_full<HT>(gh, buf.g_a[l] + row * H, h);
+            og.template from_acc<false>(gh);
+        };
+        {
+            Operand<PREC, OT> go;
+            go.template from_acc<false>(g);
+            f32x16 gh[HT];
+            zero_tiles<HT>(gh);
+            dense<OT, HT>(gh, go, WSel<PREC, false>::get(b, f.nh), lane);     // W_nh^T
+            relu_backward(gh, f.nh - 1);
         }
         for (int l = f.nh - 1; l >= 1; --l) {
             f32x16 gh[HT];
             zero_tiles<HT>(gh);
-            dense<HT, HT>(gh, og, WSel<CGNN_F32, false>::get(b, l), lane);        // W_l^T
-            f32x16 hv[HT];
-            load_rows_full<HT>(hv, buf.h[l - 1] + rowc * H, h);
-#pragma unroll
-            for (int t = 0; t < HT; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) og.v[t][i] = hv[t][i] > 0.f ? gh[t][i] : 0.f;
-            if (live) store_rows_full<HT>(og.v, buf.g_a[l - 1] + row * H, h);
+            dense<HT, HT>(gh, og, WSel<PREC, false>::get(b, l), lane);        // W_l^T
+            relu_backward(gh, l - 1);
         }
         // ------------------------------------------------------------ input gradients
         if (du1 != nullptr) {
             f32x16 gx[K1T];
             zero_tiles<K1T>(gx);
-            dense<HT, K1T>(gx, og, WSel<CGNN_F32, false>::get(b, 0), lane);       // W_0a^T
+            dense<HT, K1T>(gx, og, WSel<PREC, false>::get(b, 0), lane);       // W_0a^T
             if (live) {
                 if (in1_full && ld_du1 % 4 == 0)
                     store_rows_full<K1T>(gx, du1 + row * ld_du1, h);
@@ -300,16 +312,16 @@ __global__ __launch_bounds__(CGNN_BLOCK) void col_dot_kernel(const float* __rest
     }
 }
 
-template <int K1T, int K2T, int HT, int OT>
+template <int PREC, int K1T, int K2T, int HT, int OT>
 static int launch_bwd(bool ln, const MlpDev& f, const MlpDev& b, const void* fw2, const void* bw2, const float* u1, int ld1,
                       const float* u2, int ld2, const float* dy, int ld_dy, int64_t n, const BwdBufs& buf, float* du1,
                       int ld_du1, float* du2, int ld_du2, hipStream_t st) {
     const int grid = grid_for_tiles((n + 31) / 32);
     if (ln)
-        mlp_backward_kernel<K1T, K2T, HT, OT, true><<<grid, CGNN_BLOCK, 0, st>>>(f, b, fw2, bw2, u1, ld1, u2, ld2, dy, ld_dy,
+        mlp_backward_kernel<PREC, K1T, K2T, HT, OT, true><<<grid, CGNN_BLOCK, 0, st>>>(f, b, fw2, bw2, u1, ld1, u2, ld2, dy, ld_dy,
                                                                                n, buf, du1, ld_du1, du2, ld_du2);
     else
-        mlp_backward_kernel<K1T, K2T, HT, OT, false><<<grid, CGNN_BLOCK, 0, st>>>(f, b, fw2, bw2, u1, ld1, u2, ld2, dy,
+        mlp_backward_kernel<PREC, K1T, K2T, HT, OT, false><<<grid, CGNN_BLOCK, 0, st>>>(f, b, fw2, bw2, u1, ld1, u2, ld2, dy,
                                                                                 ld_dy, n, buf, du1, ld_du1, du2, ld_du2);
     return check_hip(hipGetLastError(), "cgnn_mlp_backward launch");
 }
@@ -329,8 +341,8 @@ int cgnn_mlp_backward(const cgnn_mlp* fwd, const cgnn_linear* fwd_part2, const c
     if (rc != CGNN_OK) return rc;
     rc = make_mlp_dev(bwd, &b, nullptr, "cgnn_mlp_backward(bwd)");
     if (rc != CGNN_OK) return rc;
-    if (fwd->precision != CGNN_F32 || bwd->precision != CGNN_F32) {
-        set_error("cgnn_mlp_backward: exact f32 (CGNN_F32) weights only");
+    if ((fwd->precision != CGNN_F32 && fwd->precision != CGNN_F32X3) || bwd->precision != fwd->precision) {
+        set_error("cgnn_mlp_backward: fwd and bwd weights must both be CGNN_F32 (exact) or both CGNN_F32X3");
         return CGNN_ERR_UNSUPPORTED;
     }
     if (!u1 || !dy || !buf || n < 0 || f.nh != b.nh || !buf->g_o || (fwd_part2 != nullptr) != (bwd_part2 != nullptr) ||
@@ -381,10 +393,13 @@ int cgnn_mlp_backward(const cgnn_mlp* fwd, const cgnn_linear* fwd_part2, const c
     const int K1T = (in1 + 31) / 32, K2T = in2 / 32, HT = hidden / 32, OT = (out_dim + 31) / 32;
     const void* fw2 = fwd_part2 ? fwd_part2->w : nullptr;
     const void* bw2 = bwd_part2 ? bwd_part2->w : nullptr;
-#define CGNN_BWD(K1, K2, Hh, Oo)                                                                                  \
-    if (K1T == K1 && K2T == K2 && HT == Hh && OT == Oo)                                                            \
-        return launch_bwd<K1, K2, Hh, Oo>(ln, f, b, fw2, bw2, u1, ld1, u2, ld2, dy, ld_dy, n, bb, du1, ld_du1, du2, \
-                                          ld_du2, st);
+    const bool x3 = fwd->precision == CGNN_F32X3;
+#define CGNN_BWD(K1, K2, Hh, Oo)                                                                                        \
+    if (K1T == K1 && K2T == K2 && HT == Hh && OT == Oo)                                                                  \
+        return x3 ? launch_bwd<CGNN_F32X3, K1, K2, Hh, Oo>(ln, f, b, fw2, bw2, u1, ld1, u2, ld2, dy, ld_dy, n, bb, du1,    \
+                                                          ld_du1, du2, ld_du2, st)                                       \
+                  : launch_bwd<CGNN_F32, K1, K2, Hh, Oo>(ln, f, b, fw2, bw2, u1, ld1, u2, ld2, dy, ld_dy, n, bb, du1,      \
+                                                        ld_du1, du2, ld_du2, st);
     // square models hidden == latent in {32, 64, 128}: node block (two inputs), encoder (narrow input), decoder
 #define CGNN_BWD_T(Tt) CGNN_BWD(Tt, Tt, Tt, Tt) CGNN_BWD(1, 0, Tt, Tt) CGNN_BWD(Tt, 0, Tt, 1)
     CGNN_BWD_T(1) CGNN_BWD_T(2) CGNN_BWD_T(4)

@@ -413,6 +413,7 @@ class EncodeProcessDecode(nn.Module):
         self.message_source = "x_j"
         self.node_precision = "fp32"
         self.edge_precision = "fp32"
+        self.train_precision = "fp32"  # arithmetic of the differentiable forward + backward: "fp32" or "fp32x3"
         self.locality_sort = True     # run in the k-NN build's spatial order when the graph carries it
         self.fuse_rounds = True       # x_j mode: all rounds of the edge stream in one launch
         # which one-launch kernel: "tile32" = cgnn_edge_stream_run (32-edge MFMA tiles, one wave per SIMD, default),
@@ -511,7 +512,7 @@ class EncodeProcessDecode(nn.Module):
 
     def _train_packs(self):
         from .training import TrainPacks
-        key = _params_key(self, "train")
+        key = _params_key(self, "train", getattr(self, "train_precision", "fp32"))
         if self._train_packed is None or self._train_packed[0] != key:
             self._train_packed = (key, TrainPacks(self))
         return self._train_packed[1]

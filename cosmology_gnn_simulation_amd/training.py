@@ -27,10 +27,13 @@ from ._lib import CgnnError
 
 
 class _TrainMLP:
-    """Forward (exact f32) and transposed packings of one ``build_mlp`` (+LayerNorm), plus its parameter list in
+    """Forward and transposed packings (exact f32, or f32 emulated by three bf16 terms) of one ``build_mlp`` (+LayerNorm), plus its parameter list in
     ``module.parameters()`` order: (w, b) per Linear, then LayerNorm (weight, bias)."""
 
-    def __init__(self, linears: Sequence[nn.Module], ln: Optional[nn.LayerNorm], split_at: Optional[int] = None):
+    def __init__(self, linears: Sequence[nn.Module], ln: Optional[nn.LayerNorm], split_at: Optional[int] = None,
+                 precision: str = "fp32"):
+        if ops._prec(precision) not in (_lib.F32, _lib.F32X3):
+            raise CgnnError(f"training arithmetic must be 'fp32' (exact) or 'fp32x3' (three bf16 terms), got {precision!r}")
         self.linears, self.ln = list(linears), ln
         self.split_at = split_at
         w0 = linears[0].weight
@@ -39,12 +42,12 @@ class _TrainMLP:
         self.in1 = int(split_at if split_at is not None else w0.shape[1])
         self.in2 = int(w0.shape[1] - self.in1)
         cols = (0, self.in1) if split_at is not None else None
-        self.fwd = ops.PackedMLP(wb, lnp, "fp32", first_layer_cols=cols)
-        self.fwd2 = ops.PackedLinear(w0, None, "fp32", self.in1, self.in2) if self.in2 else None
+        self.fwd = ops.PackedMLP(wb, lnp, precision, first_layer_cols=cols)
+        self.fwd2 = ops.PackedLinear(w0, None, precision, self.in1, self.in2) if self.in2 else None
         t = lambda w: w.detach().t().contiguous()  # noqa: E731
         tw = [(t(w0[:, :self.in1]), None)] + [(t(l.weight), None) for l in linears[1:]]
-        self.bwd = ops.PackedMLP(tw, None, "fp32")
-        self.bwd2 = ops.PackedLinear(t(w0[:, self.in1:]), None, "fp32") if self.in2 else None
+        self.bwd = ops.PackedMLP(tw, None, precision)
+        self.bwd2 = ops.PackedLinear(t(w0[:, self.in1:]), None, precision) if self.in2 else None
         self.hidden = self.fwd.hidden
         self.out_dim = self.fwd.out_dim
         self.out_padded = (self.out_dim + 31) // 32 * 32
@@ -96,10 +99,12 @@ class TrainPacks:
         from .graph_network import _split_mlp
         D = model._latent_size
         self.latent = D
-        self.enc = _TrainMLP(*_split_mlp(model.encoder.node_model))
-        self.rounds = [_TrainMLP(*_split_mlp(net.node_model), split_at=D) for net in model.processor]
-        self.dec_acc = _TrainMLP(*_split_mlp(model.decoder_acc))
-        self.dec_tr = _TrainMLP(*_split_mlp(model.decoder_temp_rate))
+        prec = getattr(model, "train_precision", "fp32")
+        self.precision = prec
+        self.enc = _TrainMLP(*_split_mlp(model.encoder.node_model), precision=prec)
+        self.rounds = [_TrainMLP(*_split_mlp(net.node_model), split_at=D, precision=prec) for net in model.processor]
+        self.dec_acc = _TrainMLP(*_split_mlp(model.decoder_acc), precision=prec)
+        self.dec_tr = _TrainMLP(*_split_mlp(model.decoder_temp_rate), precision=prec)
         self.all = [self.enc] + self.rounds + [self.dec_acc, self.dec_tr]
         for m in self.all:
             if m.hidden != D or m.hidden not in (32, 64, 128):
@@ -123,9 +128,10 @@ class _NodeStream(torch.autograd.Function):
         n = x0.shape[0]
         xs = [ops.mlp_rows(packs.enc.fwd, x0)]
         aggs = []                   # kept for the backward (N x D x 4 bytes per round; recomputing them cost 6 % of a step)
+        plan = ops.AggregatePlan.of(src, n, fixed_k, xs[0].shape[1]) if fixed_k > 0 else None
         for r in packs.rounds:
             x = xs[-1]
-            agg = ops.aggregate(x, src, dst, n, fixed_k, src.numel())
+            agg = ops.aggregate(x, src, dst, n, fixed_k, src.numel(), plan=plan)
             aggs.append(agg)
             xs.append(ops.node_block(r.fwd, r.fwd.layers[0], r.fwd2, x, agg, None, residual=True))
         acc = ops.mlp_rows(packs.dec_acc.fwd, xs[-1])

@@ -17,6 +17,7 @@ ap.add_argument("--neighbors", type=int, default=16)
 ap.add_argument("--latent", type=int, default=128)
 ap.add_argument("--mp-steps", type=int, default=10)
 ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--train-precision", default="fp32", choices=["fp32", "fp32x3"])
 a = ap.parse_args()
 dev = "cuda"
 n, k, d, L = a.particles, a.neighbors, a.latent, a.mp_steps
@@ -27,6 +28,7 @@ g = data_utils.preprocess(c[:5], e[:5], meta, c[5], e[5], 0.0, k, 0.01, 1.0)
 m = graph_network.EncodeProcessDecode(d, d, 2, L, 3)
 m.load_state_dict(synthetic.make_state_dict(d, d, 2, L, 3))
 m = m.to(dev).train()
+m.train_precision = a.train_precision
 opt = torch.optim.Adam(m.parameters(), lr=1e-4)
 mse = torch.nn.functional.mse_loss
 
