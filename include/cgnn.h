@@ -68,7 +68,7 @@ typedef enum {
 
 /* Element type / row order of the Ps, Pd gather tables (cgnn_project_nodes -> cgnn_edge_block).
  * Feature f of a row of H values:
- *   CGNN_P_F32       float32, position f                                  (mlp precision CGNN_F32)
+ *   CGNN_P_F32       float32, position f                                  (mlp precision CGNN_F32, CGNN_F16X2_N16)
  *   CGNN_P_BF16_S32  bf16, f = 32t+8g+4h+c at h*(H/2) + (4t+g)*4 + c      (mlp precision CGNN_BF16)
  *   CGNN_P_BF16_S16  bf16, f = 16O+4q+i    at (4*(O/2) + q)*8 + 4*(O%2) + i   (mlp precision CGNN_BF16_N16: the
  *                    16-edge kernel's MFMA B-operand order, so the rows enter the accumulators through the matrix pipe)
@@ -151,6 +151,10 @@ int cgnn_project_nodes(const cgnn_linear* ws, const cgnn_linear* wd, int32_t pre
  * mlp->layer[0] holds We (in_dim = D); e_out may alias e_in.
  * e_in / e_out / e_upd are CGNN_TILED32 buffers of cgnn_tiled_rows(num_edges) rows;
  * ps / pd are cgnn_project_nodes tables in the cgnn_ptable format matching mlp->precision.
+ * Kernels by mlp->precision: CGNN_F32 (exact, any compiled shape), CGNN_BF16 (32-edge tiles), CGNN_BF16_N16 (16-edge
+ * tiles; weights resident in LDS up to 128 x 128, streamed through an LDS ring at latent = hidden = 256, where the
+ * fused aggregation below is not available), CGNN_F16X2_N16 (f32 accuracy on the fp16 matrix cores, latent = hidden =
+ * 128, 1..3 hidden layers, a bias on every Linear, CGNN_P_F32 tables).
  *
  * Optional fused aggregation (agg_out != NULL; CGNN_BF16_N16 kernels, receiver-sorted edges with
  * fixed in-degree seg_k in {8, 16}): the same launch also writes the receivers' aggregate
