@@ -48,7 +48,8 @@ def _run(fmt, lin, ln, x, agg, residual=True):
 
 
 @pytest.mark.parametrize("fmt", ["fp32x3_n16", "fp16x2_n16"])
-@pytest.mark.parametrize("n,d,nh", [(1000, 128, 2), (17, 128, 2), (4099, 64, 1), (300, 32, 3), (70000, 128, 2)])
+@pytest.mark.parametrize("n,d,nh", [(1000, 128, 2), (17, 128, 2), (4099, 64, 1), (300, 32, 3), (70000, 128, 2),
+                                    (500, 128, 4), (129, 128, 1), (128, 128, 3)])      # 4 hidden layers: the two-slot kernel
 def test_node_block_f32_emulations_sit_at_f32_rounding_level(fmt, n, d, nh):
     gen = torch.Generator().manual_seed(n + d)
     lin, ln = _rand_node_mlp(gen, d, nh)
