@@ -13,7 +13,7 @@ W = 5
 @pytest.mark.parametrize("world,msg,prec", [(2, "x_j", "fp32"), (4, "x_j", "fp32"), (8, "x_j", "fp32"),
                                             (8, "edge", "fp32"), (2, "x_j", "bf16"), (8, "x_j", "bf16")])
 def test_sharded_forward_equals_unsharded(world, msg, prec):
-    """prec "bf16" = bench.py's configuration (bf16 edge MLP, three-term node path): in x_j mode every rank runs its
+    """prec "bf16" = bench.py's configuration (bf16 edge MLP, node path on two fp16 terms): in x_j mode every rank runs its
     node stream round by round (halo per round) and then ONE one-launch edge stream, as the single-GPU forward does."""
     _sharded_vs_unsharded(6000, 16, 64, 3, world, msg, prec, seed=41)
 
@@ -36,7 +36,7 @@ def _sharded_vs_unsharded(n, k, d, L, world, msg, prec, seed, full_size=False):
     model = model.to(DEV).eval()
     model.message_source = msg
     if prec == "bf16":
-        model.edge_precision, model.node_precision = "bf16", "fp32x3"
+        model.edge_precision, model.node_precision = "bf16", "fp16x2"       # bench.py's presets for cfg3-5
     with torch.no_grad():
         want = model.forward_with_latents(g)
     shards = [cdist.build_shard(g.pos, 1.0, k, world, r) for r in range(world)]
