@@ -157,7 +157,6 @@ __global__ __launch_bounds__(CGNN_R256_BLOCK) void edge_block_ring256_kernel(Rin
     __syncthreads();
     const LdsVecPtr vec = (LdsVecPtr)cgnn_smem;
     const unsigned ring_lds = (unsigned)(uintptr_t)(cgnn_smem + RING_OFF);
-    const bf16x8 sel0 = p16_selector(lane, 0), sel1 = p16_selector(lane, 1);
 
     const unsigned voff = (unsigned)wave * 1024u + (unsigned)lane * 16u;
     int slot = 0;
@@ -224,7 +223,11 @@ __global__ __launch_bounds__(CGNN_R256_BLOCK) void edge_block_ring256_kernel(Rin
                 pso[s] = __builtin_bit_cast(bf16x8, psn[s]);
                 pdo[s] = __builtin_bit_cast(bf16x8, pdn[s]);
             }
-            p16_accumulate<KS>(acc, pso, pdo, sel0, sel1);      // Linear 0's node thirds (+ b1)
+            // the two constant selector fragments are rebuilt here every step (a dozen vector instructions) instead of
+            // living in eight registers across it: the kernel sits at the 256-register limit
+            int lane_ = lane;
+            asm volatile("" : "+v"(lane_));
+            p16_accumulate<KS>(acc, pso, pdo, p16_selector(lane_, 0), p16_selector(lane_, 1));      // Linear 0's node thirds (+ b1)
         }
         operand16<false, KS>(op, ev);
         CGNN_R256_UNIT(0, acc, op)
