@@ -58,14 +58,28 @@ constexpr int VEC_BYTES = 8192;               // up to 8 vectors of 256 floats
 constexpr int RING_OFF = VEC_BYTES;
 constexpr int LDS_BYTES = RING_OFF + NS * CHUNK;    // 136 KiB
 
+// s_mov + s_nop 3: five wait states between any VALU write of the base SGPRs (a v_readlane spill reload) and the load
+// that reads them -- the compiler cannot pad inside an asm block (see f2_ring.hpp)
 __device__ __forceinline__ void dma_piece(const char* sbase, unsigned voff, unsigned lds) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds)
                  : "memory");
 }
 template <int IMM>
 __device__ __forceinline__ u32x4 load16(const void* p) {
     u32x4 r;
     asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r) : "v"(p), "n"(IMM) : "memory");
+    return r;
+}
+// wave-uniform base + one 32-bit lane offset: no 64-bit address per load (sixteen of them, computed ahead of the burst,
+// were what pushed the kernel over its 256 registers)
+__device__ __forceinline__ u32x4 load16_s(const void* base, unsigned voff) {
+    // the base is wave-uniform by construction; say so (the compiler does not always see it through the tile arithmetic)
+    const uint64_t b = (uint64_t)(uintptr_t)base;
+    const uint64_t sb = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    u32x4 r;
+    // s_nop 4: the v_readfirstlane above is a VALU write of the SGPR pair this load reads (five wait states)
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sb) : "memory");
     return r;
 }
 __device__ __forceinline__ int idx_load(const int32_t* p) {
@@ -176,6 +190,7 @@ __global__ __launch_bounds__(CGNN_R256_BLOCK) void edge_block_ring256_kernel(Rin
     };
     auto tile_offset = [&](int64_t ht) { return (ht >> 1) * (32 * D) + n16_lane_offset(c, q, (int)(ht & 1)); };
     auto clip = [&](int64_t ht) { return RAGGED && ht > last_ht ? last_ht : ht; };
+    auto lane_off = [&](int64_t ht) { return (unsigned)n16_lane_offset(c, q, (int)(ht & 1)) * 4u; };   // bytes inside the tile
 
     const int nb = gridDim.x;
     int64_t step = blockIdx.x;
@@ -186,11 +201,12 @@ __global__ __launch_bounds__(CGNN_R256_BLOCK) void edge_block_ring256_kernel(Rin
         const int64_t ec = edge_of(ht);
         int s0 = idx_load(a.src + ec), d0 = idx_load(a.dst + ec);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(s0), "+v"(d0)::"memory");
-        const float* ep = a.e_in + tile_offset(ht);
+        const float* ep = a.e_in + (ht >> 1) * (32 * D);         // wave-uniform tile base
         const __bf16* pp = a.ps + (int64_t)s0 * D + 8 * q;
         const __bf16* dp = a.pd + (int64_t)d0 * D + 8 * q;
-        static_for_each([&](auto oc) { en[decltype(oc)::value] = load16<0>(ep + n16_tile_offset(decltype(oc)::value)); },
-                        std::make_integer_sequence<int, OT>{});
+        static_for_each([&](auto oc) {
+            en[decltype(oc)::value] = load16_s(ep + n16_tile_offset(decltype(oc)::value), lane_off(ht));
+        }, std::make_integer_sequence<int, OT>{});
         static_for_each([&](auto sc) { psn[decltype(sc)::value] = load16<decltype(sc)::value * 64>(pp); },
                         std::make_integer_sequence<int, KS>{});
         static_for_each([&](auto sc) { pdn[decltype(sc)::value] = load16<decltype(sc)::value * 64>(dp); },
@@ -209,7 +225,6 @@ __global__ __launch_bounds__(CGNN_R256_BLOCK) void edge_block_ring256_kernel(Rin
         const int64_t next_step = step + nb < a.steps ? step + nb : step;
         const int64_t next2_step = next_step + nb < a.steps ? next_step + nb : next_step;
         const int64_t ht1 = clip(a.first_half_tile + next_step * WAVES + wave);
-        const int64_t ec2 = edge_of(clip(a.first_half_tile + next2_step * WAVES + wave));
 
         FragPipe pipe;
         f32x4 ev[OT], acc[OT];
@@ -246,17 +261,29 @@ __global__ __launch_bounds__(CGNN_R256_BLOCK) void edge_block_ring256_kernel(Rin
         CGNN_R256_UNIT(NU - 1, acc, op)
 
         // ---- tail ----
-        const __bf16* pp = a.ps + (int64_t)sn * D + 8 * q;      // the next tile's P rows (indices from a step ago)
-        const __bf16* dp = a.pd + (int64_t)dn * D + 8 * q;
-        sn = idx_load(a.src + ec2);                             // indices of the tile after it
-        dn = idx_load(a.dst + ec2);
+        // The lane's constants (row in the tile, feature quarter, byte offset in a tile) are recomputed here from the lane
+        // id instead of living in registers through the MFMA units: at the 256-register limit the compiler otherwise
+        // spills them, and each reload waits vmcnt(0), draining the prefetches below.
+        int tl = threadIdx.x & 63;
+        asm volatile("" : "+v"(tl));
+        const int tc = tl & 15, tq = tl >> 4;
+        const __bf16* pp = a.ps + (int64_t)sn * D + 8 * tq;     // the next tile's P rows (indices from a step ago)
+        const __bf16* dp = a.pd + (int64_t)dn * D + 8 * tq;
         {
-            const float* ep = a.e_in + tile_offset(ht1);
-            static_for_each([&](auto oc) { en[decltype(oc)::value] = load16<0>(ep + n16_tile_offset(decltype(oc)::value)); },
-                            std::make_integer_sequence<int, OT>{});
+            const int64_t e2 = clip(a.first_half_tile + next2_step * WAVES + wave) * 16 + tc;
+            const int64_t ec2 = e2 < a.num_edges ? e2 : a.num_edges - 1;
+            sn = idx_load(a.src + ec2);                         // indices of the tile after it
+            dn = idx_load(a.dst + ec2);
         }
-        layer_norm16<OT>(acc, vec + (NH + 1) * D, vec + (NH + 2) * D, q);
-        const int64_t tb = tile_offset(ht);
+        {
+            const float* ep = a.e_in + (ht1 >> 1) * (32 * D);
+            const unsigned loff = (unsigned)n16_lane_offset(tc, tq, (int)(ht1 & 1)) * 4u;
+            static_for_each([&](auto oc) {
+                en[decltype(oc)::value] = load16_s(ep + n16_tile_offset(decltype(oc)::value), loff);
+            }, std::make_integer_sequence<int, OT>{});
+        }
+        layer_norm16<OT>(acc, vec + (NH + 1) * D, vec + (NH + 2) * D, tq);
+        const int64_t tb = (ht >> 1) * (32 * D) + n16_lane_offset(tc, tq, (int)(ht & 1));
         if (valid && a.e_upd != nullptr) {   // block-uniform pointer
 #pragma unroll
             for (int o = 0; o < OT; ++o) *reinterpret_cast<f32x4*>(a.e_upd + tb + n16_tile_offset(o)) = acc[o];

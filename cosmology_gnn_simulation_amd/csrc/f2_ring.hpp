@@ -24,9 +24,14 @@ constexpr int PC = CHUNK / 1024 / WAVES;      // 1-KiB DMA pieces per wave per c
 constexpr int VEC_BYTES = 4096;               // up to 8 vectors of 128 floats, first thing in LDS
 static_assert(PC * 1024 * WAVES == CHUNK, "a chunk is a whole number of pieces per wave");
 
-// one 1-KiB piece: 64 lanes x 16 B from sbase + voff to LDS address lds (wave-uniform) + lane * 16
+// one 1-KiB piece: 64 lanes x 16 B from sbase + voff to LDS address lds (wave-uniform) + lane * 16.
+// The s_nop is not decoration.  A vector-memory instruction that reads an SGPR needs five wait states after a VALU
+// instruction wrote it (v_readlane reloading a spilled base pointer, v_readfirstlane); the compiler pads that for its
+// own instructions but cannot see inside an asm block, and with ~40 chunk base pointers live it does keep some of them
+// in VGPR lanes.  s_mov + s_nop 3 are the five states whatever stands before the block
+// (scripts/dev/scan_asm_hazards.py checks the listing; tests/test_host_logic.py runs it).
 __device__ __forceinline__ void dma_piece(const char* sbase, unsigned voff, unsigned lds) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds)
                  : "memory");
 }
 

@@ -148,3 +148,66 @@ def test_generate_metadata_matches_reference_driver():
         g = np.asarray(got[key], dtype=np.float64)
         assert g.shape == w.shape, key                       # temperature statistics are length-1 lists, the rest scalars
         assert np.allclose(g, w, rtol=1e-5, atol=1e-7), (key, g, w)
+
+
+def test_kernels_with_hand_issued_loads_use_no_scratch_and_pad_their_own_hazards(tmp_path):
+    """The ring kernels and the one-launch edge stream request rows with inline-asm loads and hand the registers over
+    behind a counted `s_waitcnt` of their own.  The compiler does not know that those registers are still in flight: if it
+    spilled one between the request and the wait it would store a stale value (and its own reloads wait vmcnt(0),
+    draining the prefetches).  So these kernels must compile without scratch: checked here from hipcc's resource remarks.
+    Nor can it pad hazards inside an asm block: a vector-memory instruction there that reads an SGPR a VALU instruction
+    wrote fewer than five wait states earlier (v_readlane of a spilled base pointer, v_readfirstlane) goes out with the
+    old address -- scripts/dev/scan_asm_hazards.py reads the listing for that."""
+    import concurrent.futures
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "cosmology_gnn_simulation_amd", "csrc")
+    sys.path.insert(0, os.path.join(ROOT, "scripts", "dev"))
+    try:
+        import scan_asm_hazards
+    finally:
+        sys.path.pop(0)
+
+    def listing(name, extra=()):
+        out = str(tmp_path / (name + ".s"))
+        cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+               "-Wno-unused-function", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", *extra, "-S",
+               os.path.join(csrc, name), "-o", out]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return name, r.stderr, out
+
+    jobs = [("node_block_f2.hip", ()), ("edge_block_f2.hip", ()), ("edge_block_ring256.hip", ()),
+            ("edge_stream32.hip", ("-mllvm", "-amdgpu-mfma-vgpr-form=1"))]
+    with concurrent.futures.ThreadPoolExecutor(4) as pool:
+        for name, text, path in pool.map(lambda j: listing(*j), jobs):
+            sizes = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", text)]
+            spills = [int(x) for x in re.findall(r"VGPRs Spill: (\d+)", text)]
+            assert sizes and spills, name
+            assert max(spills) == 0, (name, spills)
+            kernels = re.findall(r"Function Name: (\S+)", text)
+            bad = [k for k, s_ in zip(kernels, sizes) if s_ != 0 and ("ring" in k or "stream32" in k)]
+            assert not bad, (name, bad)
+            assert scan_asm_hazards.scan(path) == [], name
+
+
+def test_asm_hazard_scanner_sees_a_short_gap(tmp_path):
+    """The scanner itself: a base pointer read back from a VGPR lane two instructions before an asm load is a finding,
+    the same listing with the five wait states is not."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts", "dev"))
+    try:
+        import scan_asm_hazards
+    finally:
+        sys.path.pop(0)
+    body = ("k:\n\tv_readlane_b32 s4, v255, 2\n\tv_readlane_b32 s5, v255, 3\n\tv_mov_b32_e32 v1, v2\n\t;;#ASMSTART\n"
+            "\ts_mov_b32 m0, s6\n\ts_nop %d\n\tglobal_load_lds_dwordx4 v3, s[4:5]\n\t;;#ASMEND\n\ts_endpgm\n")
+    short, padded = tmp_path / "short.s", tmp_path / "padded.s"
+    short.write_text(body % 0)
+    padded.write_text(body % 3)
+    assert len(scan_asm_hazards.scan(str(short))) == 2          # s4 after 4 states, s5 after 3
+    assert scan_asm_hazards.scan(str(padded)) == []
