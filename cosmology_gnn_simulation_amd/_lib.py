@@ -17,15 +17,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcgnn_hip.so")
 
 MAX_HIDDEN_LAYERS = 6
-F32, BF16, BF16_N16, F32X3, F32X3_N16, F16X2_N16 = 0, 1, 2, 3, 4, 5  # cgnn_precision
+F32, BF16, BF16_N16, F32X3, F32X3_N16, F16X2_N16, F16X2 = 0, 1, 2, 3, 4, 5, 6  # cgnn_precision
 N16_NODE = (F32X3_N16, F16X2_N16)       # node-kernel packings whose epilogue fuses the next round's projections
 P_F32, P_BF16_S32, P_BF16_S16 = 0, 1, 2  # cgnn_ptable
 LDS_WEIGHT_BUDGET = 152 * 1024           # CGNN_LDS_WEIGHT_BUDGET in csrc/mlp_device.hpp
 PRECISIONS = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "bf16_n16": BF16_N16,
               "fp32x3": F32X3, "f32x3": F32X3, "fp32x3_n16": F32X3_N16, "fp16x2_n16": F16X2_N16,
-              # "fp16x2" = f32-level accuracy from two fp16 terms where a kernel has that form (the processor's node
-              # blocks: graph_network._PackedProcessor picks "fp16x2_n16"); everywhere else the three-bf16-term form
-              "fp16x2": F32X3, "f16x2": F32X3}
+              # "fp16x2" = f32-level accuracy from two fp16 terms: the 32-row packing, accepted wherever "fp32x3" is
+              # (graph_network._PackedProcessor swaps in "fp16x2_n16" where the 16-row ring kernels apply)
+              "fp16x2": F16X2, "f16x2": F16X2}
+F32_EMULATED = (F32X3, F16X2)           # 32-row packings that emulate f32 on the bf16 / fp16 matrix cores
 
 # every symbol include/cgnn.h declares (tests check the library exports all of them)
 EXPORTS = (

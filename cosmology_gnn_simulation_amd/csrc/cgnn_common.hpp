@@ -73,6 +73,7 @@ __device__ __forceinline__ int feat_of(int t, int h, int i) { return 32 * t + 8 
 // ---------------------------------------------------------------------------
 // MFMA operands
 // ---------------------------------------------------------------------------
+typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
 template <int PREC, int T>
 struct Operand;
 
@@ -135,6 +136,60 @@ struct Operand<CGNN_F32X3, T> {
     }
 };
 
+// f32 emulated with two fp16 terms (CGNN_F16X2; the arithmetic is described at CGNN_F16X2 in n16.hpp):
+//   x = hi + lo / 2048,  hi = fp16(x),  lo = fp16((x - hi) * 2048);  three products per element, the two that carry one
+// scaled term summed in a second accumulator that dense() folds in with weight 2^-11.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+struct f16x8x2 {
+    f16x8 p[2];
+};
+#define CGNN_F16X2_SCALE 2048.0f
+#define CGNN_F16X2_INV_SCALE (1.0f / 2048.0f)
+
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_));
+}
+
+// two values -> (hi pair, lo pair)
+__device__ __forceinline__ void split_f16x2(float a, float b, unsigned& hi, unsigned& lo) {
+    typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+    hi = pack_f16(a, b);
+    const f16x2_ h = __builtin_bit_cast(f16x2_, hi);
+    lo = pack_f16((a - (float)h[0]) * CGNN_F16X2_SCALE, (b - (float)h[1]) * CGNN_F16X2_SCALE);
+}
+
+
+template <int T>
+struct Operand<CGNN_F16X2, T> {
+    f16x8 v[2][2 * T];
+    template <bool RELU>
+    __device__ __forceinline__ void from_acc(const f32x16 (&acc)[T]) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                u32x4_ hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a = acc[t][8 * s + 2 * j], b = acc[t][8 * s + 2 * j + 1];
+                    if (RELU) {     // NaN stays NaN (fmaxf would turn it into 0 and hide an fp16 overflow)
+                        a = a < 0.f ? 0.f : a;
+                        b = b < 0.f ? 0.f : b;
+                    }
+                    unsigned h, l;
+                    split_f16x2(a, b, h, l);
+                    hi[j] = h;
+                    lo[j] = l;
+                }
+                v[0][2 * t + s] = __builtin_bit_cast(f16x8, hi);
+                v[1][2 * t + s] = __builtin_bit_cast(f16x8, lo);
+            }
+    }
+};
+
 // out[o] += W[o-tile, :] . in   for every out tile; wp = packed weights.
 //
 // The packed layout is flat in MFMA issue order: fragment m = (o*KT + kt)*S + s lives at wp[m*64 + lane]
@@ -166,6 +221,24 @@ struct Frag<CGNN_F32X3> {
     static constexpr int GS = 2;
     static constexpr int NB = 3;    // weights stream from L2 at one wave per SIMD: keep two groups in flight
 };
+
+template <>
+struct Frag<CGNN_F16X2> {
+    typedef f16x8x2 type;
+    static constexpr int S = 2;
+    static constexpr int GS = 4;
+    static constexpr int NB = 3;
+};
+
+// hi.hi into c0; hi.lo and lo.hi (both scaled by 2^11) into c1
+template <int KT>
+__device__ __forceinline__ void mfma_step2(const f16x8x2& a, const Operand<CGNN_F16X2, KT>& in, int kt, int s, f32x16& c0,
+                                           f32x16& c1) {
+    const int i = 2 * kt + s;
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.p[0], in.v[0][i], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.p[0], in.v[1][i], c1, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.p[1], in.v[0][i], c1, 0, 0, 0);
+}
 
 template <int KT>
 __device__ __forceinline__ f32x16 mfma_step(const bf16x8x3& a, const Operand<CGNN_F32X3, KT>& in, int kt, int s,
@@ -230,6 +303,20 @@ struct BufW<CGNN_F32X3> {
         return r;
     }
 };
+template <>
+struct BufW<CGNN_F16X2> {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ BufW(const void* p, unsigned bytes)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000)) {}
+    __device__ __forceinline__ f16x8x2 fetch(int m, int lane) const {
+        f16x8x2 r;
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+            r.p[part] = __builtin_bit_cast(
+                f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, (m * 2 + part) * 1024, 0));
+        return r;
+    }
+};
 struct LdsW {
     LdsWeightPtr p;
     __device__ __forceinline__ explicit LdsW(LdsWeightPtr q) : p(q) {}
@@ -246,6 +333,10 @@ __device__ __forceinline__ void dense(f32x16 (&out)[OT], const Operand<PREC, KT>
     constexpr int NB = Frag<PREC>::NB;      // ring depth: NB - 1 groups of fragments in flight ahead of the MFMAs
     static_assert(M % GS == 0, "group size must divide the MFMA count");
     A buf[NB][GS];
+    // CGNN_F16X2: second accumulator for the products scaled by 2^11.  An output tile's MFMAs are consecutive, so two
+    // of them (alternating by tile) are enough: zeroed at the tile's first fragment, folded in after its last.
+    constexpr bool TWO = PREC == CGNN_F16X2;
+    f32x16 c1[2];
 #pragma unroll
     for (int p = 0; p < NB - 1; ++p)
         if (p < NG) {
@@ -262,7 +353,16 @@ __device__ __forceinline__ void dense(f32x16 (&out)[OT], const Operand<PREC, KT>
         for (int j = 0; j < GS; ++j) {
             const int m = g * GS + j;
             const int o = m / (KT * S), kt = (m / S) % KT, s = m % S;
-            out[o] = mfma_step<KT>(buf[g % NB][j], in, kt, s, out[o]);
+            if constexpr (TWO) {
+                if (m % (KT * S) == 0) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) c1[o & 1][i] = 0.f;
+                }
+                mfma_step2<KT>(buf[g % NB][j], in, kt, s, out[o], c1[o & 1]);
+                if (m % (KT * S) == KT * S - 1) out[o] += c1[o & 1] * CGNN_F16X2_INV_SCALE;
+            } else {
+                out[o] = mfma_step<KT>(buf[g % NB][j], in, kt, s, out[o]);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -278,6 +378,7 @@ __device__ __forceinline__ void dense_part(f32x16 (&out)[OT], const Operand<PREC
     constexpr int GS = (M < Frag<PREC>::GS) ? M : Frag<PREC>::GS;
     constexpr int NG = M / GS;
     static_assert(M % GS == 0 && M1 <= OT * KT * S, "bad fragment range");
+    static_assert(PREC != CGNN_F16X2, "the two-accumulator form has no chunked variant in the 32-row layout");
     A buf[2][GS];
 #pragma unroll
     for (int j = 0; j < GS; ++j) buf[0][j] = wp.fetch(j, lane);

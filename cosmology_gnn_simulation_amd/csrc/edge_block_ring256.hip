@@ -188,7 +188,6 @@ __global__ __launch_bounds__(CGNN_R256_BLOCK) void edge_block_ring256_kernel(Rin
         const int64_t e = ht * 16 + c;
         return e < a.num_edges ? e : a.num_edges - 1;
     };
-    auto tile_offset = [&](int64_t ht) { return (ht >> 1) * (32 * D) + n16_lane_offset(c, q, (int)(ht & 1)); };
     auto clip = [&](int64_t ht) { return RAGGED && ht > last_ht ? last_ht : ht; };
     auto lane_off = [&](int64_t ht) { return (unsigned)n16_lane_offset(c, q, (int)(ht & 1)) * 4u; };   // bytes inside the tile
 

@@ -35,7 +35,7 @@ inline int make_mlp_dev(const cgnn_mlp* m, MlpDev* d, size_t* lds_bytes, const c
         set_error("%s: num_hidden_layers=%d outside [1,%d]", who, m->num_hidden_layers, CGNN_MAX_HIDDEN_LAYERS);
         return CGNN_ERR_UNSUPPORTED;
     }
-    if (m->precision < CGNN_F32 || m->precision > CGNN_F16X2_N16) {
+    if (m->precision < CGNN_F32 || m->precision > CGNN_F16X2) {
         set_error("%s: unknown precision %d", who, m->precision);
         return CGNN_ERR_INVALID_ARG;
     }

@@ -183,9 +183,11 @@ int cgnn_mlp_rows(const cgnn_mlp* mlp, const float* x, int64_t n, int32_t ld_x, 
     CGNN_TRY(CGNN_F32, 1, H, D)       \
     CGNN_TRY(CGNN_BF16, 1, H, D)      \
     CGNN_TRY(CGNN_F32X3, 1, H, D)     \
+    CGNN_TRY(CGNN_F16X2, 1, H, D)     \
     CGNN_TRY(CGNN_F32, D, H, 1)       \
     CGNN_TRY(CGNN_BF16, D, H, 1)      \
-    CGNN_TRY(CGNN_F32X3, D, H, 1)
+    CGNN_TRY(CGNN_F32X3, D, H, 1)     \
+    CGNN_TRY(CGNN_F16X2, D, H, 1)
     CGNN_FOR_EACH_PAIR(CGNN_PAIR)
 #undef CGNN_PAIR
 #undef CGNN_TRY
@@ -218,15 +220,18 @@ int cgnn_project_nodes(const cgnn_linear* ws, const cgnn_linear* wd, int32_t pre
     const void* wsp = ps ? ws->w : nullptr;
     const void* wdp = pd ? wd->w : nullptr;
     const float* bd = pd ? wd->b : nullptr;
-    if ((precision == CGNN_F32) != (p_format == CGNN_P_F32) ||
-        (precision != CGNN_F32 && precision != CGNN_BF16) ||
+    const bool f32_like = precision == CGNN_F32 || precision == CGNN_F16X2;     // both write CGNN_P_F32 tables
+    if (f32_like != (p_format == CGNN_P_F32) || (!f32_like && precision != CGNN_BF16) ||
         (p_format != CGNN_P_F32 && p_format != CGNN_P_BF16_S32 && p_format != CGNN_P_BF16_S16)) {
         set_error("cgnn_project_nodes: precision %d / p_format %d combination is not supported", precision, p_format);
         return CGNN_ERR_INVALID_ARG;
     }
 #define CGNN_PAIR(Hh, Dd)                                                                                          \
     if (HT == Hh && DT == Dd) {                                                                                     \
-        if (p_format == CGNN_P_F32)                                                                                 \
+        if (p_format == CGNN_P_F32 && precision == CGNN_F16X2)                                                      \
+            project_kernel<CGNN_F16X2, CGNN_P_F32, Dd, Hh><<<grid, CGNN_BLOCK, 0, st>>>(wsp, wdp, bd, H, x, n,       \
+                                                                                       (float*)ps, (float*)pd);    \
+        else if (p_format == CGNN_P_F32)                                                                            \
             project_kernel<CGNN_F32, CGNN_P_F32, Dd, Hh><<<grid, CGNN_BLOCK, 0, st>>>(wsp, wdp, bd, H, x, n,         \
                                                                                      (float*)ps, (float*)pd);      \
         else if (p_format == CGNN_P_BF16_S32)                                                                       \

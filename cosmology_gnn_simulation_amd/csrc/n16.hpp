@@ -441,28 +441,7 @@ __device__ __forceinline__ void dense16x3_part(f32x4 (&out)[OT], const bf16x8 (&
 // scripts/dev/probe_f16_mfma.hip), so tiny values only lose the bits below 2^-35.  The one thing fp16 cannot hold is
 // |x| >= 65520: hi becomes inf and the row's results are inf/NaN (visible, never silently wrong).  Latents behind a
 // LayerNorm and sums of <= 64 of them are orders of magnitude below that; CGNN_F32X3 has the f32 range.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-struct f16x8x2 {
-    f16x8 p[2];
-};
-#define CGNN_F16X2_SCALE 2048.0f
-#define CGNN_F16X2_INV_SCALE (1.0f / 2048.0f)
-
-__device__ __forceinline__ unsigned pack_f16(float a, float b) {
-    typedef float f32x2_ __attribute__((ext_vector_type(2)));
-    typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
-    const f32x2_ v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_));
-}
-
-// two values -> (hi pair, lo pair)
-__device__ __forceinline__ void split_f16x2(float a, float b, unsigned& hi, unsigned& lo) {
-    typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
-    hi = pack_f16(a, b);
-    const f16x2_ h = __builtin_bit_cast(f16x2_, hi);
-    lo = pack_f16((a - (float)h[0]) * CGNN_F16X2_SCALE, (b - (float)h[1]) * CGNN_F16X2_SCALE);
-}
-
+// (f16x8, f16x8x2, pack_f16, split_f16x2: cgnn_common.hpp, shared with the 32-row form CGNN_F16X2)
 template <bool RELU, int KS>
 __device__ __forceinline__ void operand16f2(f16x8 (&op)[2][KS], const f32x4 (&acc)[2 * KS]) {
 #pragma unroll

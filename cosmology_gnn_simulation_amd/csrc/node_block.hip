@@ -316,6 +316,9 @@ extern "C" int cgnn_node_block(const cgnn_mlp* mlp, const cgnn_linear* w_x, cons
         else if (prec == CGNN_F32X3)                                                                                \
             node_block_kernel<CGNN_F32X3, Hh, Dd><<<grid, CGNN_BLOCK, 0, st>>>(m, w_x->w, w_agg->w, b1, x, agg, n,   \
                                                                               x_out, residual);                    \
+        else if (prec == CGNN_F16X2)                                                                                \
+            node_block_kernel<CGNN_F16X2, Hh, Dd><<<grid, CGNN_BLOCK, 0, st>>>(m, w_x->w, w_agg->w, b1, x, agg, n,   \
+                                                                              x_out, residual);                    \
         else                                                                                                        \
             node_block_kernel<CGNN_BF16, Hh, Dd><<<grid, CGNN_BLOCK, 0, st>>>(m, w_x->w, w_agg->w, b1, x, agg, n,    \
                                                                              x_out, residual);                     \

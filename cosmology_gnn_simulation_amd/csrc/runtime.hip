@@ -105,6 +105,28 @@ __global__ void pack_f32x3_kernel(const float* __restrict__ w, int out_dim, int 
     wp[idx] = part == 0 ? w1 : (part == 1 ? w2 : w3);
 }
 
+// CGNN_F16X2: the same fragment layout with two fp16 parts, [m][part][lane][j]: part 0 = fp16(w), part 1 =
+// fp16((w - part0) * 2048)  (cgnn_common.hpp)
+__global__ void pack_f16x2_kernel(const float* __restrict__ w, int out_dim, int ld, int col0, int ncols, int KT,
+                                  int64_t total, _Float16* __restrict__ wp) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int j = (int)(idx & 7);
+    const int l = (int)((idx >> 3) & 63);
+    const int64_t mp = idx >> 9;
+    const int part = (int)(mp & 1);
+    const int64_t m = mp >> 1;
+    const int s = (int)(m & 1);
+    const int64_t okt = m >> 1;
+    const int kt = (int)(okt % KT);
+    const int o = (int)(okt / KT);
+    const int row = 32 * o + (l & 31);
+    const int k = 32 * kt + 16 * s + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+    const float v = (row < out_dim && k < ncols) ? w[(int64_t)row * ld + col0 + k] : 0.f;
+    const _Float16 hi = (_Float16)v;
+    wp[idx] = part == 0 ? hi : (_Float16)((v - (float)hi) * 2048.0f);
+}
+
 // CGNN_BF16_N16: fragment m = O * KS + s (16-feature out tile O, 32-wide k-step s), A[row][k] of
 // v_mfma_f32_16x16x32_bf16: lane l holds row l & 15, k = 8 (l >> 4) + j  <->  feature phi(s, l >> 4, j) (n16.hpp)
 __global__ void pack_bf16_n16_kernel(const float* __restrict__ w, int out_dim, int ld, int col0, int ncols, int KS,
@@ -582,6 +604,12 @@ int cgnn_pack_linear(const float* w, int32_t out_dim, int32_t ld, int32_t col0, 
         const int64_t tot16 = (int64_t)((out_dim + 15) / 16) * KT * 512;
         pack_bf16_n16_kernel<<<(unsigned)((tot16 + CGNN_BLOCK - 1) / CGNN_BLOCK), CGNN_BLOCK, 0, st>>>(
             w, out_dim, ld, col0, ncols, KT, tot16, (__bf16*)packed);
+        return check_hip(hipGetLastError(), "cgnn_pack_linear launch");
+    }
+    if (precision == CGNN_F16X2) {
+        const int64_t tot2 = (int64_t)OT * KT * 1024 * 2;
+        pack_f16x2_kernel<<<(unsigned)((tot2 + CGNN_BLOCK - 1) / CGNN_BLOCK), CGNN_BLOCK, 0, st>>>(
+            w, out_dim, ld, col0, ncols, KT, tot2, (_Float16*)packed);
         return check_hip(hipGetLastError(), "cgnn_pack_linear launch");
     }
     if (precision == CGNN_F32X3) {

@@ -233,7 +233,8 @@ class _PackedProcessor:
             # f32 Ps / Pd tables); other shapes take the exact-f32 kernels
             e_lins = _split_mlp(net.edge_model)[0]
             fits = D == 128 and w1e.shape[0] == 128 and len(e_lins) - 1 <= 3 and all(l.bias is not None for l in e_lins)
-            proj_precision, edge_precision = "fp32", ("fp16x2_n16" if fits else "fp32")
+            two_terms = str(edge_precision).lower() in ("fp16x2", "f16x2")
+            proj_precision, edge_precision = ("fp16x2" if two_terms else "fp32"), ("fp16x2_n16" if fits else "fp32")
         else:
             proj_precision = edge_precision
         self.ws = ops.PackedLinear(w1e, None, proj_precision, 0, D)
@@ -251,9 +252,9 @@ class _PackedProcessor:
         self.p_dtype = ops.p_table_dtype(self.edge.precision)
         # cat([x, aggregated]) -> [Wx | Wa]                         (reference graph_network.py:94)
         node_fmt = node_precision
-        if ops._prec(node_precision) == _lib.F32X3 and D <= 128 and w1n.shape[0] == D:
+        if ops._prec(node_precision) in _lib.F32_EMULATED and D <= 128 and w1n.shape[0] == D:
             # square layers <= 128: the 16-row, two-waves-per-SIMD node kernel, on two fp16 or three bf16 terms
-            node_fmt = "fp16x2_n16" if str(node_precision).lower() in ("fp16x2", "f16x2") else "fp32x3_n16"
+            node_fmt = "fp16x2_n16" if ops._prec(node_precision) == _lib.F16X2 else "fp32x3_n16"
         self.wx = ops.PackedLinear(w1n, b1n, node_fmt, 0, D)
         self.wa = ops.PackedLinear(w1n, None, node_fmt, D, D)
         self.node = _pack_mlp(net.node_model, node_fmt, first_layer_cols=(0, D))

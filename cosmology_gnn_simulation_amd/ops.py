@@ -220,12 +220,12 @@ def mlp_rows(mlp: PackedMLP, x: torch.Tensor, out=None, tiled: bool = False):
 def p_table_format(edge_mlp_precision) -> int:
     """``cgnn_ptable`` format the edge kernel of this precision gathers from (include/cgnn.h)."""
     return {F32: _lib.P_F32, BF16: _lib.P_BF16_S32, BF16_N16: _lib.P_BF16_S16,
-            _lib.F16X2_N16: _lib.P_F32}[_prec(edge_mlp_precision)]
+            _lib.F16X2_N16: _lib.P_F32, _lib.F16X2: _lib.P_F32}[_prec(edge_mlp_precision)]
 
 
 def p_table_dtype(edge_mlp_precision) -> torch.dtype:
     """Element type of the Ps/Pd gather tables (engine-internal layout, see include/cgnn.h)."""
-    return torch.float32 if _prec(edge_mlp_precision) in (F32, _lib.F16X2_N16) else torch.bfloat16
+    return torch.float32 if _prec(edge_mlp_precision) in (F32, _lib.F16X2_N16, _lib.F16X2) else torch.bfloat16
 
 
 def project_nodes(ws: Optional[PackedLinear], wd: Optional[PackedLinear], x: torch.Tensor,

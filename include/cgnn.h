@@ -55,7 +55,7 @@ typedef enum {
     CGNN_F32X3_N16 = 4, /* CGNN_F32X3 arithmetic, weights packed for the 16-row-per-wave node kernel
                           (v_mfma_f32_16x16x32_bf16, two waves per SIMD); cgnn_node_block only,
                           square layers, its projection epilogue takes CGNN_BF16_N16 weights    */
-    CGNN_F16X2_N16 = 5  /* f32 emulated on the fp16 matrix cores (v_mfma_f32_16x16x32_f16): operands split
+    CGNN_F16X2_N16 = 5, /* f32 emulated on the fp16 matrix cores (v_mfma_f32_16x16x32_f16): operands split
                           into two fp16 terms, x = hi + lo/2048 with lo = fp16((x - hi) * 2048) (11 + 11
                           significand bits, the residual scaled so it stays a normal fp16 number); three
                           products per element (hi.hi, hi.lo, lo.hi; lo.lo <= 2^-22 relative dropped), the
@@ -64,11 +64,15 @@ typedef enum {
                           row turns into inf/NaN (never a silently wrong number); use CGNN_F32X3 for
                           unnormalised inputs.  16-row packing; cgnn_node_block (square layers <= 128,
                           projection epilogue CGNN_BF16_N16) and cgnn_edge_block                  */
+    CGNN_F16X2 = 6      /* the same two-fp16-term arithmetic in the 32-row packing (v_mfma_f32_32x32x16_f16):
+                          wherever CGNN_F32X3 is accepted -- cgnn_mlp_rows, cgnn_node_block (any supported
+                          latent / hidden pair), cgnn_project_nodes (CGNN_P_F32 tables), cgnn_mlp_backward --
+                          at half its matrix work; same range limit as CGNN_F16X2_N16              */
 } cgnn_precision;
 
 /* Element type / row order of the Ps, Pd gather tables (cgnn_project_nodes -> cgnn_edge_block).
  * Feature f of a row of H values:
- *   CGNN_P_F32       float32, position f                                  (mlp precision CGNN_F32, CGNN_F16X2_N16)
+ *   CGNN_P_F32       float32, position f                                  (mlp precision CGNN_F32, CGNN_F16X2, CGNN_F16X2_N16)
  *   CGNN_P_BF16_S32  bf16, f = 32t+8g+4h+c at h*(H/2) + (4t+g)*4 + c      (mlp precision CGNN_BF16)
  *   CGNN_P_BF16_S16  bf16, f = 16O+4q+i    at (4*(O/2) + q)*8 + 4*(O%2) + i   (mlp precision CGNN_BF16_N16: the
  *                    16-edge kernel's MFMA B-operand order, so the rows enter the accumulators through the matrix pipe)

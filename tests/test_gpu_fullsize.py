@@ -197,7 +197,7 @@ def test_cfg5_shape_kernel_by_kernel_and_forward():
     m = graph_network.EncodeProcessDecode(d, d, 2, L, 3)
     m.load_state_dict(sd)
     m = m.to(DEV).eval()
-    m.edge_precision, m.node_precision = "bf16", "fp16x2"        # bench.py's cfg5 preset (at 256 the node path is three-term)
+    m.edge_precision, m.node_precision = "bf16", "fp16x2"        # bench.py's cfg5 preset (at 256: the 32-row two-fp16-term node kernel)
     src, dst, fk = graph_network._graph_arrays(g, n)
     assert fk == k
     P = m._pack(17, 4)

@@ -133,3 +133,51 @@ def test_node_block_fused_projection_epilogue(fmt, p_format):
         diff = (a.float() - b.float()).abs()
         assert float(diff.max()) <= 2.0 ** -7 * float(b.float().abs().max())      # at most a bf16 rounding flip
         assert float((diff > 0).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize("n,d,h,nh", [(1000, 256, 256, 2), (333, 64, 128, 2), (70, 256, 128, 1), (2000, 128, 128, 2)])
+def test_node_block_fp16x2_32_row_packing(n, d, h, nh):
+    """CGNN_F16X2 (the two-fp16-term arithmetic in the 32-row packing, any supported latent / hidden pair): f32 rounding
+    level against float64, like the three-bf16-term form it replaces at half the matrix work."""
+    gen = torch.Generator().manual_seed(n + d + h)
+    dims = [2 * d] + [h] * nh + [d]
+    lin = []
+    for i in range(nh + 1):
+        bound = 1.0 / np.sqrt(dims[i])
+        lin.append((((torch.rand(dims[i + 1], dims[i], generator=gen) * 2 - 1) * bound).to(DEV),
+                    ((torch.rand(dims[i + 1], generator=gen) * 2 - 1) * bound).to(DEV)))
+    ln = ((1 + 0.1 * torch.randn(d, generator=gen)).to(DEV), (0.1 * torch.randn(d, generator=gen)).to(DEV))
+    x = torch.randn(n, d, generator=gen).to(DEV) * 2
+    agg = torch.randn(n, d, generator=gen).to(DEV) * 8
+    want = _f64(lin, ln, x, agg)
+    got = _run("fp16x2", lin, ln, x, agg).double()
+    exact = _run("fp32", lin, ln, x, agg).double()
+    three = _run("fp32x3", lin, ln, x, agg).double()
+    scale = float(want.abs().max())
+    err, err_exact, err3 = (float((t - want).abs().max()) / scale for t in (got, exact, three))
+    assert err <= 2e-6, (err, err_exact, err3)
+    assert err <= 4 * max(err_exact, err3) + 2e-7, (err, err_exact, err3)
+
+
+@pytest.mark.parametrize("d,h", [(128, 128), (256, 256), (64, 128)])
+def test_project_nodes_fp16x2_writes_f32_tables(d, h):
+    """cgnn_project_nodes with CGNN_F16X2 weights: CGNN_P_F32 tables at f32 rounding level (the exact-f32 kernel's
+    tables are the comparison; the edge kernels that gather f32 rows take either)."""
+    n = 1500
+    gen = torch.Generator().manual_seed(d + h)
+    w = ((torch.rand(h, 3 * d, generator=gen) * 2 - 1) / np.sqrt(3 * d)).to(DEV)
+    b = ((torch.rand(h, generator=gen) * 2 - 1) / np.sqrt(3 * d)).to(DEV)
+    x = (torch.randn(n, d, generator=gen) * 3).to(DEV)
+    tabs = {}
+    for prec in ("fp32", "fp16x2"):
+        ws, wd = ops.PackedLinear(w, None, prec, 0, d), ops.PackedLinear(w, b, prec, d, d)
+        tabs[prec] = ops.project_nodes(ws, wd, x)
+    torch.cuda.synchronize()
+    want_s = x.double() @ w[:, :d].double().t()
+    want_d = x.double() @ w[:, d:2 * d].double().t() + b.double()
+    for (got, want) in ((tabs["fp16x2"][0], want_s), (tabs["fp16x2"][1], want_d)):
+        assert got.dtype == torch.float32
+        assert float((got.double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    with pytest.raises(_lib.CgnnError):
+        ops.project_nodes(ops.PackedLinear(w, None, "fp16x2", 0, d), ops.PackedLinear(w, b, "fp16x2", d, d), x,
+                          p_format=_lib.P_BF16_S32)

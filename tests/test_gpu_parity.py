@@ -36,7 +36,7 @@ def _graph(g):
                                                   (333, 17, 128, 128, 1, True), (257, 128, 128, 3, 2, False),
                                                   (64, 64, 64, 1, 3, False), (100, 17, 128, 64, 2, True),
                                                   (40, 9, 256, 256, 2, True)])
-@pytest.mark.parametrize("prec,tol", [("fp32", 2e-6), ("fp32x3", 2e-6), ("bf16", 3e-2)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-6), ("fp32x3", 2e-6), ("fp16x2", 2e-6), ("bf16", 3e-2)])
 def test_mlp_rows(n, fin, hid, out, nh, ln, prec, tol):
     gen = torch.Generator().manual_seed(n + fin)
     lin, sd, dims = [], {}, [fin] + [hid] * nh + [out]
@@ -631,7 +631,10 @@ def test_on_device_rollout_matches_restatement():
                                                           (128, 128, 16, 3, 2, "bf16", "fp32x3"),       # 3 hidden layers
                                                           (128, 128, 16, 2, 3, "fp16x2", "fp16x2"),     # cfg2's fast path
                                                           (128, 128, 8, 1, 2, "fp16x2", "fp16x2"),
-                                                          (64, 64, 8, 2, 2, "fp16x2", "fp16x2")])       # falls back to f32 edges
+                                                          (64, 64, 8, 2, 2, "fp16x2", "fp16x2"),        # falls back to f32 edges
+                                                          (256, 256, 32, 2, 2, "bf16", "fp16x2"),       # cfg5 preset: 32-row fp16x2 node path
+                                                          (256, 128, 16, 1, 2, "fp16x2", "fp16x2"),
+                                                          (64, 128, 8, 2, 2, "fp16x2", "fp16x2")])
 def test_model_other_shapes_vs_oracle(d, h, k, nh, L, edge_prec, node_prec):
     """Shapes beyond the committed fixtures (README.md:59-62 ranges; BASELINE cfg5 = latent 256, k 32): the HIP
     forward against the oracle on a fresh graph."""
