@@ -668,14 +668,32 @@ def mlp_backward(fwd: PackedMLP, fwd2: Optional[PackedLinear], bwd: PackedMLP, b
     return du1, du2
 
 
+_WGRAD_WORKSPACE = {}       # device -> workspace of cgnn_weight_grad_x3 (68 MB, contents irrelevant between calls)
+
+
 def weight_grad(g: torch.Tensor, ld_g: int, out_dim: int, a: torch.Tensor, in_dim: int, n: int, dw: torch.Tensor,
-                col0: int = 0, db: Optional[torch.Tensor] = None) -> torch.Tensor:
+                col0: int = 0, db: Optional[torch.Tensor] = None, precision="fp32") -> torch.Tensor:
     """``dw[:, col0:col0+in_dim] += g[:n, :out_dim]^T a[:n, :in_dim]`` (``dw`` contiguous float32, pre-zeroed by the
-    caller on first use); ``db`` (optional, pre-zeroed) ``+= `` the column sums of ``g``."""
+    caller on first use); ``db`` (optional, pre-zeroed) ``+= `` the column sums of ``g``.  ``precision="fp32x3"``: a
+    128 x 128 product of 16-byte-aligned operands runs on the bf16 matrix cores (three bf16 terms per operand) with a
+    fixed summation order (``cgnn_weight_grad_x3``); every other shape takes the f32-MFMA kernel."""
     require_device(g, "g")
     a = f32c(a, "a")
     if dw.dtype != torch.float32 or not dw.is_contiguous() or dw.shape[0] != out_dim:
         raise CgnnError("weight_grad: dw must be contiguous float32 [out_dim, >= col0 + in_dim]")
+    if _prec(precision) == _lib.F32X3 and out_dim == 128 and in_dim == 128 and ld_g % 4 == 0 and \
+            a.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0 and a.data_ptr() % 16 == 0:
+        lib = _lib.load()
+        key = (a.device.type, a.device.index)
+        ws = _WGRAD_WORKSPACE.get(key)
+        if ws is None:
+            ws = _WGRAD_WORKSPACE[key] = torch.empty(lib.cgnn_weight_grad_x3_workspace_bytes(), dtype=torch.uint8,
+                                                     device=a.device)
+        with _timed("weight_grad", a.device):
+            check(lib.cgnn_weight_grad_x3(g.data_ptr(), ld_g, a.data_ptr(), a.stride(0), n, dw.data_ptr(), dw.stride(0),
+                                          col0, ptr(db), ws.data_ptr(), ws.numel(), stream_ptr(a.device)),
+                  "cgnn_weight_grad_x3")
+        return dw
     with _timed("weight_grad", a.device):
         check(_lib.load().cgnn_weight_grad(g.data_ptr(), ld_g, out_dim, a.data_ptr(), a.stride(0), in_dim, n,
                                            dw.data_ptr(), dw.stride(0), col0, ptr(db), stream_ptr(a.device)),

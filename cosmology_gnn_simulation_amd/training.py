@@ -36,6 +36,7 @@ class _TrainMLP:
             raise CgnnError(f"training arithmetic must be 'fp32' (exact) or 'fp32x3' (three bf16 terms), got {precision!r}")
         self.linears, self.ln = list(linears), ln
         self.split_at = split_at
+        self.precision = precision
         w0 = linears[0].weight
         wb = [(l.weight, l.bias) for l in linears]
         lnp = None if ln is None else (ln.weight, ln.bias)
@@ -77,11 +78,11 @@ class _TrainMLP:
             dw = torch.zeros_like(lin.weight, memory_format=torch.contiguous_format)
             db = torch.zeros(out_dim, dtype=torch.float32, device=dw.device)
             if l == 0:
-                ops.weight_grad(g, ld_g, out_dim, u1, self.in1, n, dw, 0, db)
+                ops.weight_grad(g, ld_g, out_dim, u1, self.in1, n, dw, 0, db, self.precision)
                 if u2 is not None:
-                    ops.weight_grad(g, ld_g, out_dim, u2, self.in2, n, dw, self.in1)
+                    ops.weight_grad(g, ld_g, out_dim, u2, self.in2, n, dw, self.in1, None, self.precision)
             else:
-                ops.weight_grad(g, ld_g, out_dim, scratch.h[l - 1], H, n, dw, 0, db)
+                ops.weight_grad(g, ld_g, out_dim, scratch.h[l - 1], H, n, dw, 0, db, self.precision)
             grads += [dw, db]
         if self.ln is not None:
             dgamma = torch.zeros(self.out_dim, dtype=torch.float32, device=dy.device)

@@ -291,6 +291,17 @@ int cgnn_mlp_backward(const cgnn_mlp* fwd, const cgnn_linear* fwd_part2, const c
 int cgnn_weight_grad(const float* g, int32_t ld_g, int32_t out_dim, const float* a, int32_t ld_a, int32_t in_dim,
                      int64_t n, float* dw, int32_t ld_dw, int32_t col0, float* db, void* stream);
 
+/* The same reduction for a 128 x 128 Linear (out_dim == in_dim == 128) on the bf16 matrix cores, reproducible:
+ * g and a are split into three bf16 terms in registers (six products, f32 accumulation: f32-level error, f32 exponent
+ * range), every wave keeps the whole 128 x 128 product of its row range, writes it to `workspace`
+ * (cgnn_weight_grad_x3_workspace_bytes() bytes, device memory, contents irrelevant) and a second kernel adds the
+ * partial products in a fixed order: dw[o, col0 + i] += ..., db[o] += ... (db may be NULL) with the same bits on
+ * every run.  g and a must be 16-byte aligned with ld_g % 4 == ld_a % 4 == 0 (else CGNN_ERR_UNSUPPORTED: use
+ * cgnn_weight_grad). */
+size_t cgnn_weight_grad_x3_workspace_bytes(void);
+int cgnn_weight_grad_x3(const float* g, int32_t ld_g, const float* a, int32_t ld_a, int64_t n, float* dw, int32_t ld_dw,
+                        int32_t col0, float* db, void* workspace, size_t workspace_bytes, void* stream);
+
 /* out[c] += sum_r a[r, c] * (b ? b[r, c] : 1)   for c < width (bias / LayerNorm-affine gradients). */
 int cgnn_col_dot(const float* a, int32_t ld_a, const float* b, int32_t ld_b, int64_t n, int32_t width, float* out,
                  void* stream);

@@ -71,6 +71,42 @@ def test_mlp_backward_matches_autograd(n, fin, fin2, hid, out, nh, ln, precision
         assert _close(g, sd[name].grad), name
 
 
+@pytest.mark.parametrize("n,col0,scale", [(1, 0, 1.0), (5000, 128, 1.0), (1025, 0, 1e-7), (70001, 0, 1.0), (33, 64, 1e3)])
+def test_weight_grad_three_bf16_terms_is_f32_accurate_and_reproducible(n, col0, scale):
+    """cgnn_weight_grad_x3 (128 x 128, precision="fp32x3"): the bf16-matrix-core reduction against float64, no worse than
+    the f32-MFMA kernel; tiny gradients (1e-7: far below fp16's range, fine for bf16's) keep their accuracy; the same
+    bits on every run (fixed summation order, where the f32 kernel adds row chunks with atomics)."""
+    gen = torch.Generator().manual_seed(n + col0)
+    g = (torch.randn(n, 128, generator=gen) * scale).to(DEV)
+    a = torch.randn(n, 128, generator=gen).to(DEV)
+    want = g.double().t() @ a.double()
+    want_b = g.double().sum(0)
+    outs = []
+    for _ in range(2):
+        dw = torch.zeros(128, col0 + 128, device=DEV)
+        db = torch.zeros(128, device=DEV)
+        ops.weight_grad(g, 128, 128, a, 128, n, dw, col0, db, "fp32x3")
+        outs.append((dw, db))
+    dw, db = outs[0]
+    assert torch.equal(dw, outs[1][0]) and torch.equal(db, outs[1][1])
+    assert float(dw[:, :col0].abs().sum()) == 0.0
+    ref = torch.zeros(128, col0 + 128, device=DEV)
+    ops.weight_grad(g, 128, 128, a, 128, n, ref, col0, None)                    # the f32-MFMA kernel
+    scale_w = float(want.abs().max())
+    err = float((dw[:, col0:].double() - want).abs().max()) / scale_w
+    err_ref = float((ref[:, col0:].double() - want).abs().max()) / scale_w
+    assert err <= 2e-6 and err <= 4 * err_ref + 2e-7, (err, err_ref)
+    assert _close(db, want_b, 1e-5)
+    # accumulates into dw like the f32 kernel
+    ops.weight_grad(g, 128, 128, a, 128, n, dw, col0, None, "fp32x3")
+    assert float((dw[:, col0:].double() - 2 * want).abs().max()) <= 4e-6 * scale_w
+    # shapes it does not take (here 128 x 64) run the f32 kernel under the same call
+    dw2 = torch.zeros(128, 64, device=DEV)
+    a64 = a[:, :64].contiguous()
+    ops.weight_grad(g, 128, 128, a64, 64, n, dw2, 0, None, "fp32x3")
+    assert _close(dw2, g.double().t() @ a64.double(), 1e-5)
+
+
 def test_mlp_backward_rejects_unsupported_shapes():
     from cosmology_gnn_simulation_amd.training import _TrainMLP
     gen = torch.Generator().manual_seed(0)
