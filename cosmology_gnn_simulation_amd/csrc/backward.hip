@@ -255,10 +255,12 @@ __global__ __launch_bounds__(CGNN_BLOCK) void weight_grad_kernel(const float* __
 // out[c] += sum_r a[r,c] (* b[r,c]): lanes take 4 columns x 1 row each (16-byte loads when aligned), the row lanes
 // of a workgroup meet in LDS, one atomic per column per workgroup.
 #define CGNN_COLDOT_ROWS 512
+template <bool BOTH>      // BOTH: out2[c] += sum_r a[r,c] as well (a is read once for the two sums)
 __global__ __launch_bounds__(CGNN_BLOCK) void col_dot_kernel(const float* __restrict__ a, int ld_a,
                                                              const float* __restrict__ b, int ld_b, int64_t n,
-                                                             int width, float* __restrict__ out) {
-    __shared__ float red[CGNN_BLOCK][4];
+                                                             int width, float* __restrict__ out,
+                                                             float* __restrict__ out2) {
+    __shared__ float red[CGNN_BLOCK][BOTH ? 8 : 4];
     const int c4n = (width + 3) / 4;                 // 4-column groups (<= 64 handled per pass)
     const int64_t r0 = (int64_t)blockIdx.x * CGNN_COLDOT_ROWS;
     const int64_t r1 = r0 + CGNN_COLDOT_ROWS < n ? r0 + CGNN_COLDOT_ROWS : n;
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(CGNN_BLOCK) void col_dot_kernel(const float* __rest
         const int rl = CGNN_BLOCK / cols;                          // row lanes
         const int cg = threadIdx.x % cols, rlane = threadIdx.x / cols;
         const int c = 4 * (c0 + cg);
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        float s[4] = {0.f, 0.f, 0.f, 0.f}, t[4] = {0.f, 0.f, 0.f, 0.f};
         if (cg < groups) {
             for (int64_t r = r0 + rlane; r < r1; r += rl) {
                 float va[4], vb[4] = {1.f, 1.f, 1.f, 1.f};
@@ -292,22 +294,31 @@ __global__ __launch_bounds__(CGNN_BLOCK) void col_dot_kernel(const float* __rest
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) s[j] += va[j] * vb[j];
+                for (int j = 0; j < 4; ++j) {
+                    s[j] += va[j] * vb[j];
+                    if (BOTH) t[j] += va[j];
+                }
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) red[threadIdx.x][j] = s[j];
+        for (int j = 0; j < 4; ++j) {
+            red[threadIdx.x][j] = s[j];
+            if (BOTH) red[threadIdx.x][4 + j] = t[j];
+        }
         __syncthreads();
         for (int off = rl / 2; off > 0; off >>= 1) {
             if (rlane < off)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) red[threadIdx.x][j] += red[threadIdx.x + off * cols][j];
+                for (int j = 0; j < (BOTH ? 8 : 4); ++j) red[threadIdx.x][j] += red[threadIdx.x + off * cols][j];
             __syncthreads();
         }
         if (rlane == 0 && cg < groups)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (c + j < width) atomicAdd(out + c + j, red[threadIdx.x][j]);
+                if (c + j < width) {
+                    atomicAdd(out + c + j, red[threadIdx.x][j]);
+                    if (BOTH) atomicAdd(out2 + c + j, red[threadIdx.x][4 + j]);
+                }
         __syncthreads();
     }
 }
@@ -444,9 +455,21 @@ int cgnn_col_dot(const float* a, int32_t ld_a, const float* b, int32_t ld_b, int
         return CGNN_ERR_INVALID_ARG;
     }
     if (n == 0) return CGNN_OK;
-    col_dot_kernel<<<(unsigned)((n + CGNN_COLDOT_ROWS - 1) / CGNN_COLDOT_ROWS), CGNN_BLOCK, 0, (hipStream_t)stream>>>(
-        a, ld_a, b, ld_b, n, width, out);
+    col_dot_kernel<false><<<(unsigned)((n + CGNN_COLDOT_ROWS - 1) / CGNN_COLDOT_ROWS), CGNN_BLOCK, 0,
+                            (hipStream_t)stream>>>(a, ld_a, b, ld_b, n, width, out, nullptr);
     return check_hip(hipGetLastError(), "cgnn_col_dot launch");
+}
+
+int cgnn_col_dot2(const float* a, int32_t ld_a, const float* b, int32_t ld_b, int64_t n, int32_t width, float* out_ab,
+                  float* out_a, void* stream) {
+    if (!a || !b || !out_ab || !out_a || width <= 0 || n < 0 || ld_a < width || ld_b < width) {
+        set_error("cgnn_col_dot2: invalid argument");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if (n == 0) return CGNN_OK;
+    col_dot_kernel<true><<<(unsigned)((n + CGNN_COLDOT_ROWS - 1) / CGNN_COLDOT_ROWS), CGNN_BLOCK, 0,
+                           (hipStream_t)stream>>>(a, ld_a, b, ld_b, n, width, out_ab, out_a);
+    return check_hip(hipGetLastError(), "cgnn_col_dot2 launch");
 }
 
 }  // extern "C"

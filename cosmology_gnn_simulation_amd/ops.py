@@ -744,3 +744,18 @@ def col_dot(a: torch.Tensor, ld_a: int, b: Optional[torch.Tensor], ld_b: int, n:
         check(_lib.load().cgnn_col_dot(a.data_ptr(), ld_a, ptr(b), ld_b, n, width, out.data_ptr(),
                                        stream_ptr(a.device)), "cgnn_col_dot")
     return out
+
+
+def col_dot2(a: torch.Tensor, ld_a: int, b: torch.Tensor, ld_b: int, n: int, width: int, out_ab: torch.Tensor,
+             out_a: torch.Tensor):
+    """``out_ab[c] += sum_r a[r, c] * b[r, c]`` and ``out_a[c] += sum_r a[r, c]`` in one pass over ``a`` (LayerNorm's
+    ``dgamma`` and ``dbeta`` from ``dy`` and ``zhat``)."""
+    require_device(a, "a")
+    require_device(b, "b")
+    for t in (out_ab, out_a):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() < width:
+            raise CgnnError("col_dot2: outputs must be contiguous float32 [width]")
+    with _timed("col_dot", a.device):
+        check(_lib.load().cgnn_col_dot2(a.data_ptr(), ld_a, b.data_ptr(), ld_b, n, width, out_ab.data_ptr(),
+                                        out_a.data_ptr(), stream_ptr(a.device)), "cgnn_col_dot2")
+    return out_ab, out_a

@@ -45,6 +45,18 @@ class _TrainMLP:
         cols = (0, self.in1) if split_at is not None else None
         self.fwd = ops.PackedMLP(wb, lnp, precision, first_layer_cols=cols)
         self.fwd2 = ops.PackedLinear(w0, None, precision, self.in1, self.in2) if self.in2 else None
+        # The differentiable forward only has to hand f32-accurate activations to the backward (which recomputes its
+        # own from ``fwd``): under the emulated arithmetic it runs on the forward's fastest f32-accurate kernels, the
+        # two-fp16-term ones (latents behind a LayerNorm are O(1); the encoder, which sees raw features, and the
+        # gradients, which are tiny, never pass through them).
+        self.run, self.run2 = self.fwd, self.fwd2
+        if ops._prec(precision) == _lib.F32X3:
+            square = self.in2 == self.in1 == int(w0.shape[0]) and self.in1 in (32, 64, 128) and ln is not None and \
+                all(int(l.weight.shape[0]) == self.in1 == int(l.weight.shape[1]) for l in linears[1:])
+            fast = "fp16x2_n16" if square else "fp16x2"
+            if square or self.in2 == 0:
+                self.run = ops.PackedMLP(wb, lnp, fast, first_layer_cols=cols)
+                self.run2 = ops.PackedLinear(w0, None, fast, self.in1, self.in2) if self.in2 else None
         t = lambda w: w.detach().t().contiguous()  # noqa: E731
         tw = [(t(w0[:, :self.in1]), None)] + [(t(l.weight), None) for l in linears[1:]]
         self.bwd = ops.PackedMLP(tw, None, precision)
@@ -87,8 +99,7 @@ class _TrainMLP:
         if self.ln is not None:
             dgamma = torch.zeros(self.out_dim, dtype=torch.float32, device=dy.device)
             dbeta = torch.zeros_like(dgamma)
-            ops.col_dot(dy, dy.stride(0), scratch.zhat, self.out_padded, n, self.out_dim, dgamma)
-            ops.col_dot(dy, dy.stride(0), None, 0, n, self.out_dim, dbeta)
+            ops.col_dot2(dy, dy.stride(0), scratch.zhat, self.out_padded, n, self.out_dim, dgamma, dbeta)
             grads += [dgamma, dbeta]
         return du1, du2, grads
 
@@ -127,16 +138,16 @@ class _NodeStream(torch.autograd.Function):
     def forward(ctx, packs: TrainPacks, graph, x0: torch.Tensor, *params: torch.Tensor):
         src, dst, fixed_k, _ = graph
         n = x0.shape[0]
-        xs = [ops.mlp_rows(packs.enc.fwd, x0)]
+        xs = [ops.mlp_rows(packs.enc.fwd, x0)]      # raw features: keep the f32 exponent range (three bf16 terms)
         aggs = []                   # kept for the backward (N x D x 4 bytes per round; recomputing them cost 6 % of a step)
         plan = ops.AggregatePlan.of(src, n, fixed_k, xs[0].shape[1]) if fixed_k > 0 else None
         for r in packs.rounds:
             x = xs[-1]
             agg = ops.aggregate(x, src, dst, n, fixed_k, src.numel(), plan=plan)
             aggs.append(agg)
-            xs.append(ops.node_block(r.fwd, r.fwd.layers[0], r.fwd2, x, agg, None, residual=True))
-        acc = ops.mlp_rows(packs.dec_acc.fwd, xs[-1])
-        tr = ops.mlp_rows(packs.dec_tr.fwd, xs[-1])
+            xs.append(ops.node_block(r.run, r.run.layers[0], r.run2, x, agg, None, residual=True))
+        acc = ops.mlp_rows(packs.dec_acc.run, xs[-1])
+        tr = ops.mlp_rows(packs.dec_tr.run, xs[-1])
         ctx.packs, ctx.graph, ctx.x0, ctx.xs, ctx.aggs = packs, graph, x0, xs, aggs
         return acc, tr
 

@@ -305,6 +305,10 @@ int cgnn_weight_grad_x3(const float* g, int32_t ld_g, const float* a, int32_t ld
 /* out[c] += sum_r a[r, c] * (b ? b[r, c] : 1)   for c < width (bias / LayerNorm-affine gradients). */
 int cgnn_col_dot(const float* a, int32_t ld_a, const float* b, int32_t ld_b, int64_t n, int32_t width, float* out,
                  void* stream);
+/* Both LayerNorm-affine gradients from one pass over dy: out_ab[c] += sum_r a[r, c] * b[r, c] (dgamma, a = dy,
+ * b = zhat) and out_a[c] += sum_r a[r, c] (dbeta). */
+int cgnn_col_dot2(const float* a, int32_t ld_a, const float* b, int32_t ld_b, int64_t n, int32_t width, float* out_ab,
+                  float* out_a, void* stream);
 
 /* ---- transpose of the aggregation (backward of graph_network.py:92 `propagate`) --------------------------------
  * cgnn_csr_build groups an edge list by `key`: row_ptr[r]..row_ptr[r+1] delimit, in col[], the `val` (or, when val

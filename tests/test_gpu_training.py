@@ -173,6 +173,10 @@ def test_weight_grad_and_col_dot(n, out, fin, col0):
     ops.col_dot(a.to(DEV), fin, None, 0, n, fin, o2)
     assert _close(o1, (a.double() * b.double()).sum(0), 1e-5)
     assert _close(o2, a.double().sum(0), 1e-5)
+    o3, o4 = torch.zeros(fin, device=DEV), torch.zeros(fin, device=DEV)
+    ops.col_dot2(a.to(DEV), fin, b.to(DEV), fin, n, fin, o3, o4)               # both sums from one pass
+    assert _close(o3, (a.double() * b.double()).sum(0), 1e-5)
+    assert _close(o4, a.double().sum(0), 1e-5)
 
 
 def _problem(n, k, latent, nh, steps, seed, window=5):
