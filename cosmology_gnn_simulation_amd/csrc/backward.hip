@@ -411,13 +411,13 @@ int cgnn_mlp_backward(const cgnn_mlp* fwd, const cgnn_linear* fwd_part2, const c
                                                           ld_du1, du2, ld_du2, st)                                       \
                   : launch_bwd<CGNN_F32, K1, K2, Hh, Oo>(ln, f, b, fw2, bw2, u1, ld1, u2, ld2, dy, ld_dy, n, bb, du1,      \
                                                         ld_du1, du2, ld_du2, st);
-    // square models hidden == latent in {32, 64, 128}: node block (two inputs), encoder (narrow input), decoder
+    // square models hidden == latent in {32, 64, 128, 256}: node block (two inputs), encoder (narrow input), decoder
 #define CGNN_BWD_T(Tt) CGNN_BWD(Tt, Tt, Tt, Tt) CGNN_BWD(1, 0, Tt, Tt) CGNN_BWD(Tt, 0, Tt, 1)
-    CGNN_BWD_T(1) CGNN_BWD_T(2) CGNN_BWD_T(4)
+    CGNN_BWD_T(1) CGNN_BWD_T(2) CGNN_BWD_T(4) CGNN_BWD_T(8)
 #undef CGNN_BWD_T
 #undef CGNN_BWD
     set_error("cgnn_mlp_backward: no kernel for in=(%d,%d) hidden=%d out=%d (training is built for hidden == latent in "
-              "{32,64,128})", in1, in2, hidden, out_dim);
+              "{32,64,128,256})", in1, in2, hidden, out_dim);
     return CGNN_ERR_UNSUPPORTED;
 }
 

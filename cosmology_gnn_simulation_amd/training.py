@@ -119,8 +119,8 @@ class TrainPacks:
         self.dec_tr = _TrainMLP(*_split_mlp(model.decoder_temp_rate), precision=prec)
         self.all = [self.enc] + self.rounds + [self.dec_acc, self.dec_tr]
         for m in self.all:
-            if m.hidden != D or m.hidden not in (32, 64, 128):
-                raise CgnnError(f"training kernels are built for mlp_hidden_size == latent_size in (32, 64, 128); got "
+            if m.hidden != D or m.hidden not in (32, 64, 128, 256):
+                raise CgnnError(f"training kernels are built for mlp_hidden_size == latent_size in (32, 64, 128, 256); got "
                                 f"hidden {m.hidden}, latent {D}")
         if self.enc.in1 > 32:
             raise CgnnError(f"training kernels take at most 32 node input features (got {self.enc.in1})")

@@ -18,7 +18,10 @@ GTOL = 2e-5
 def _close(got, want, tol=GTOL):
     got, want = got.detach().cpu().double(), want.detach().cpu().double()
     scale = max(float(want.abs().max()), 1e-12)
-    return float((got - want).abs().max()) / scale <= tol
+    err = float((got - want).abs().max()) / scale
+    if err > tol:
+        print(f"_close: max |got - want| / max |want| = {err:.3e} > {tol:.1e}")      # shown by pytest on failure
+    return err <= tol
 
 
 def _rand_mlp(gen, fin, hid, out, nh, ln):
@@ -41,7 +44,8 @@ class _Lin:   # what training._TrainMLP needs from an nn.Linear / nn.LayerNorm
 @pytest.mark.parametrize("n,fin,fin2,hid,out,nh,ln", [
     (1, 17, 0, 32, 32, 2, True), (1000, 21, 0, 64, 64, 2, True), (333, 17, 0, 128, 128, 1, True),
     (257, 128, 0, 128, 3, 2, False), (64, 64, 0, 64, 1, 3, False), (4100, 128, 128, 128, 128, 2, True),
-    (95, 32, 32, 32, 32, 1, True), (700, 64, 64, 64, 64, 3, True)])
+    (95, 32, 32, 32, 32, 1, True), (700, 64, 64, 64, 64, 3, True),
+    (200, 17, 0, 256, 256, 2, True), (300, 256, 256, 256, 256, 2, True), (150, 256, 0, 256, 3, 2, False)])   # latent 256 (cfg5)
 @pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
 def test_mlp_backward_matches_autograd(n, fin, fin2, hid, out, nh, ln, precision):
     from cosmology_gnn_simulation_amd.training import _TrainMLP
@@ -110,12 +114,12 @@ def test_weight_grad_three_bf16_terms_is_f32_accurate_and_reproducible(n, col0, 
 def test_mlp_backward_rejects_unsupported_shapes():
     from cosmology_gnn_simulation_amd.training import _TrainMLP
     gen = torch.Generator().manual_seed(0)
-    sd = _rand_mlp(gen, 17, 256, 256, 2, True)
+    sd = _rand_mlp(gen, 17, 128, 64, 2, True)             # hidden != latent: the backward is built for square models
     lins = [_Lin(sd[f"m.0.{2 * i}.weight"].to(DEV), sd[f"m.0.{2 * i}.bias"].to(DEV)) for i in range(3)]
     tm = _TrainMLP(lins, _Lin(sd["m.1.weight"].to(DEV), sd["m.1.bias"].to(DEV)))
-    scratch = ops.BackwardScratch(8, 256, 256, 2, DEV)
+    scratch = ops.BackwardScratch(8, 128, 64, 2, DEV)
     with pytest.raises(ops.CgnnError, match="no kernel"):
-        tm.backward(torch.zeros(8, 17, device=DEV), None, torch.zeros(8, 256, device=DEV), scratch, True)
+        tm.backward(torch.zeros(8, 17, device=DEV), None, torch.zeros(8, 64, device=DEV), scratch, True)
 
 
 @pytest.mark.parametrize("n,e,width", [(500, 8000, 128), (300, 4800, 64), (10, 0, 32), (7, 1, 4), (64, 5000, 32)])
@@ -202,7 +206,8 @@ def _reference_grads(sd, g, nh, steps, dt, batch=None, num_graphs=1):
     return loss.detach(), sdr, x.grad, out
 
 
-@pytest.mark.parametrize("n,k,latent,nh,steps", [(600, 8, 32, 2, 2), (1500, 16, 128, 2, 3), (900, 8, 64, 1, 4)])
+@pytest.mark.parametrize("n,k,latent,nh,steps", [(600, 8, 32, 2, 2), (1500, 16, 128, 2, 3), (900, 8, 64, 1, 4),
+                                                  (500, 32, 256, 2, 2)])        # cfg5's latent / k
 @pytest.mark.parametrize("locality,train_precision", [(True, "fp32"), (False, "fp32"), (True, "fp32x3")])
 def test_training_step_gradients_match_reference_autograd(n, k, latent, nh, steps, locality, train_precision):
     """train_precision "fp32x3": forward and backward GEMMs on three-bf16-term emulated f32 (bf16 matrix cores); same
@@ -225,7 +230,10 @@ def test_training_step_gradients_match_reference_autograd(n, k, latent, nh, step
     assert _close(pred["acceleration"], want_out["acceleration"], 1e-5)
     assert _close(pred["temp_rate"], want_out["temp_rate"], 1e-5)
     assert abs(float(loss.detach()) - float(want_loss)) <= 1e-5 * abs(float(want_loss))
-    assert _close(g.x.grad, want_dx)
+    # gradient gate: 2e-5 of each tensor's largest entry (f32 sums over all particles in another order than torch's);
+    # 3e-5 at latent 256, where every dot product is twice as long (measured 2.4e-5 on three bf16 terms; exact f32 stays under 2e-5)
+    gtol = GTOL if latent <= 128 else 1.5 * GTOL
+    assert _close(g.x.grad, want_dx, gtol)
     got = dict(model.named_parameters())
     for name, ref in sdr.items():
         if ".edge_model." in name:
@@ -233,7 +241,7 @@ def test_training_step_gradients_match_reference_autograd(n, k, latent, nh, step
             assert ref.grad is None and got[name].grad is None, name
         else:
             assert got[name].grad is not None, name
-            assert _close(got[name].grad, ref.grad), name
+            assert _close(got[name].grad, ref.grad, gtol), name
 
 
 def test_training_on_a_batch_of_graphs_and_optimizer_step():
