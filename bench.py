@@ -190,9 +190,8 @@ def cpu_baseline(args, dev_outputs=None):
 
 def _traffic(key, kernel):
     """HBM bytes per launch from the PMC passes committed under profiles/ (profiles/traffic.json).  An entry is only
-    reported while the kernel source it was measured on is unchanged (sha256 of the .hip file): a stale number is
-    worse than none."""
-    import hashlib
+    reported while the kernel source it was measured on is unchanged (sha256 of the .hip file and the headers it
+    includes): a stale number is worse than none."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         db = json.load(open(path))
@@ -201,14 +200,34 @@ def _traffic(key, kernel):
     ent = db.get(key)
     if not isinstance(ent, dict):
         return None
-    src = os.path.join(ROOT, "cosmology_gnn_simulation_amd", "csrc", ent.get("source", ""))
     try:
-        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+        sha = kernel_source_sha16(ent.get("source", ""))
     except OSError:
         return None
     if sha != ent.get("source_sha16"):
         return None
     return ent.get("hbm_bytes_per_launch")
+
+
+def kernel_source_sha16(name):
+    """sha256 (first 16 hex digits) of a kernel source file together with every csrc header it includes, directly or
+    not, and include/cgnn.h: the key under which profiles/traffic.json remembers what a PMC pass was measured on."""
+    import hashlib
+    import re
+    csrc = os.path.join(ROOT, "cosmology_gnn_simulation_amd", "csrc")
+    seen, todo = [], [name]
+    while todo:
+        f = todo.pop()
+        if f in seen:
+            continue
+        seen.append(f)
+        text = open(os.path.join(csrc, f), "r").read()
+        todo += [h for h in re.findall(r'#include "([^"]+)"', text) if os.path.exists(os.path.join(csrc, h))]
+    h = hashlib.sha256()
+    for f in sorted(seen):
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "cgnn.h"), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _check_against_unsharded(args, model, sharded, runner, dev, rank, world, meta, k):
