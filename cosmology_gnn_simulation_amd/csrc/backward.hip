@@ -28,9 +28,12 @@ __device__ __forceinline__ void zero_tiles(f32x16 (&a)[T]) {
 }
 
 // K1T / K2T: 32-feature tiles of the two input parts (K2T = 0: single input); HT hidden tiles; OT output tiles.
-// PREC: CGNN_F32 (v_mfma_f32_32x32x2_f32, exact) or CGNN_F32X3 (f32 emulated by three bf16 terms, six bf16 MFMAs per
+// PF / PB: arithmetic of the recomputed forward / of the gradient chain.  (F32, F32) exact; (F32X3, F32X3) three bf16
+// terms; (F16X2, F32X3): the forward recomputation -- activations of O(1) behind a LayerNorm -- on two fp16 terms (half
+// the matrix work), the gradients, which can be 1e-8, on three bf16 terms (f32 exponent range).
+// CGNN_F32 (v_mfma_f32_32x32x2_f32, exact) or CGNN_F32X3 (f32 emulated by three bf16 terms, six bf16 MFMAs per
 // product block, f32-level error: the activations and gradients stay f32 tiles, only the MFMA operands are split).
-template <int PREC, int K1T, int K2T, int HT, int OT, bool LN>
+template <int PF, int PB, int K1T, int K2T, int HT, int OT, bool LN>
 __global__ __launch_bounds__(CGNN_BLOCK) void mlp_backward_kernel(
     MlpDev f, MlpDev b, const void* f_w2, const void* b_w2, const float* __restrict__ u1, int ld1,
     const float* __restrict__ u2, int ld2, const float* __restrict__ dy, int ld_dy, int64_t n, BwdBufs buf,
@@ -41,20 +44,21 @@ __global__ __launch_bounds__(CGNN_BLOCK) void mlp_backward_kernel(
     constexpr int K2 = K2T > 0 ? K2T : 1;
     const int in1 = f.in_dim[0], out_dim = f.out_dim[f.nh];
     const bool in1_full = (in1 == 32 * K1T) && (ld1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(u1) & 15) == 0);
-    constexpr unsigned TILE_BYTES = PREC == CGNN_F32X3 ? 6144u : 4096u;      // one packed 32 x 32 weight tile
-    const BufW<PREC> fw2(f_w2, K2 * HT * TILE_BYTES), bw2(b_w2, K2 * HT * TILE_BYTES);
+    constexpr unsigned TILE_F = PF == CGNN_F32X3 ? 6144u : 4096u, TILE_B = PB == CGNN_F32X3 ? 6144u : 4096u;   // one packed 32 x 32 tile
+    const BufW<PF> fw2(f_w2, K2 * HT * TILE_F);
+    const BufW<PB> bw2(b_w2, K2 * HT * TILE_B);
     const TileRange tr = tile_range(tiles);
     for (int64_t tile = tr.first; tile < tr.end; tile += tr.stride) {
         const int64_t row = tile * 32 + r;
         const bool live = row < n;
         const int64_t rowc = live ? row : n - 1;
         // ------------------------------------------------------------ forward, recomputed
-        Operand<PREC, HT> oph;
+        Operand<PF, HT> oph;
         auto relu_store = [&](f32x16 (&acc)[HT], float* dst) __attribute__((always_inline)) {
 #pragma unroll
             for (int t = 0; t < HT; ++t)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[t][i] = fmaxf(acc[t][i], 0.f);
+                for (int i = 0; i < 16; ++i) acc[t][i] = acc[t][i] < 0.f ? 0.f : acc[t][i];     // NaN stays NaN (an fp16 overflow must show)
             if (live) store_rows_full<HT>(acc, dst + row * H, h);
             oph.template from_acc<false>(acc);
         };
@@ -67,14 +71,14 @@ __global__ __launch_bounds__(CGNN_BLOCK) void mlp_backward_kernel(
                     load_rows_full<K1T>(t1, u1 + rowc * ld1, h);
                 else
                     load_rows_ragged<K1T>(t1, u1 + rowc * ld1, in1, h);
-                Operand<PREC, K1T> op;
+                Operand<PF, K1T> op;
                 op.template from_acc<false>(t1);
-                dense<K1T, HT>(acc, op, WSel<PREC, false>::get(f, 0), lane);
+                dense<K1T, HT>(acc, op, WSel<PF, false>::get(f, 0), lane);
             }
             if (K2T > 0) {
                 f32x16 t2[K2];
                 load_rows_full<K2>(t2, u2 + rowc * ld2, h);
-                Operand<PREC, K2> op;
+                Operand<PF, K2> op;
                 op.template from_acc<false>(t2);
                 dense<K2, HT>(acc, op, fw2, lane);
             }
@@ -83,14 +87,14 @@ __global__ __launch_bounds__(CGNN_BLOCK) void mlp_backward_kernel(
         for (int l = 1; l < f.nh; ++l) {
             f32x16 acc[HT];
             acc_fill_bias<HT>(acc, f.b[l], H, h);
-            dense<HT, HT>(acc, oph, WSel<PREC, false>::get(f, l), lane);
+            dense<HT, HT>(acc, oph, WSel<PF, false>::get(f, l), lane);
             relu_store(acc, buf.h[l]);
         }
         f32x16 g[OT];      // becomes dL/d(pre-LayerNorm output)
         {
             f32x16 out[OT];
             acc_fill_bias<OT>(out, f.b[f.nh], out_dim, h);
-            dense<HT, OT>(out, oph, WSel<PREC, false>::get(f, f.nh), lane);
+            dense<HT, OT>(out, oph, WSel<PF, false>::get(f, f.nh), lane);
             // -------------------------------------------------------- output gradient through LayerNorm
             if (out_dim == OW && ld_dy % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0)
                 load_rows_full<OT>(g, dy + rowc * ld_dy, h);
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(CGNN_BLOCK) void mlp_backward_kernel(
         }
         if (live) store_rows_full<OT>(g, buf.g_o + row * OW, h);
         // ------------------------------------------------------------ backward through the hidden layers
-        Operand<PREC, HT> og;     // dL/d(pre-activation) of the layer being left
+        Operand<PB, HT> og;     // dL/d(pre-activation) of the layer being left
         // gh = W^T g of the layer above; mask by the (stored) activation's sign, keep as g_a[l], make it the next operand
         auto relu_backward = [&](f32x16 (&gh)[HT], int l) __attribute__((always_inline)) {
             f32x16 hv[HT];
@@ -157,24 +161,24 @@ __global__ __launch_bounds__(CGNN_BLOCK) void mlp_backward_kernel(
             og.template from_acc<false>(gh);
         };
         {
-            Operand<PREC, OT> go;
+            Operand<PB, OT> go;
             go.template from_acc<false>(g);
             f32x16 gh[HT];
             zero_tiles<HT>(gh);
-            dense<OT, HT>(gh, go, WSel<PREC, false>::get(b, f.nh), lane);     // W_nh^T
+            dense<OT, HT>(gh, go, WSel<PB, false>::get(b, f.nh), lane);     // W_nh^T
             relu_backward(gh, f.nh - 1);
         }
         for (int l = f.nh - 1; l >= 1; --l) {
             f32x16 gh[HT];
             zero_tiles<HT>(gh);
-            dense<HT, HT>(gh, og, WSel<PREC, false>::get(b, l), lane);        // W_l^T
+            dense<HT, HT>(gh, og, WSel<PB, false>::get(b, l), lane);        // W_l^T
             relu_backward(gh, l - 1);
         }
         // ------------------------------------------------------------ input gradients
         if (du1 != nullptr) {
             f32x16 gx[K1T];
             zero_tiles<K1T>(gx);
-            dense<HT, K1T>(gx, og, WSel<PREC, false>::get(b, 0), lane);       // W_0a^T
+            dense<HT, K1T>(gx, og, WSel<PB, false>::get(b, 0), lane);       // W_0a^T
             if (live) {
                 if (in1_full && ld_du1 % 4 == 0)
                     store_rows_full<K1T>(gx, du1 + row * ld_du1, h);
@@ -323,16 +327,16 @@ __global__ __launch_bounds__(CGNN_BLOCK) void col_dot_kernel(const float* __rest
     }
 }
 
-template <int PREC, int K1T, int K2T, int HT, int OT>
+template <int PF, int PB, int K1T, int K2T, int HT, int OT>
 static int launch_bwd(bool ln, const MlpDev& f, const MlpDev& b, const void* fw2, const void* bw2, const float* u1, int ld1,
                       const float* u2, int ld2, const float* dy, int ld_dy, int64_t n, const BwdBufs& buf, float* du1,
                       int ld_du1, float* du2, int ld_du2, hipStream_t st) {
     const int grid = grid_for_tiles((n + 31) / 32);
     if (ln)
-        mlp_backward_kernel<PREC, K1T, K2T, HT, OT, true><<<grid, CGNN_BLOCK, 0, st>>>(f, b, fw2, bw2, u1, ld1, u2, ld2, dy, ld_dy,
+        mlp_backward_kernel<PF, PB, K1T, K2T, HT, OT, true><<<grid, CGNN_BLOCK, 0, st>>>(f, b, fw2, bw2, u1, ld1, u2, ld2, dy, ld_dy,
                                                                                n, buf, du1, ld_du1, du2, ld_du2);
     else
-        mlp_backward_kernel<PREC, K1T, K2T, HT, OT, false><<<grid, CGNN_BLOCK, 0, st>>>(f, b, fw2, bw2, u1, ld1, u2, ld2, dy,
+        mlp_backward_kernel<PF, PB, K1T, K2T, HT, OT, false><<<grid, CGNN_BLOCK, 0, st>>>(f, b, fw2, bw2, u1, ld1, u2, ld2, dy,
                                                                                 ld_dy, n, buf, du1, ld_du1, du2, ld_du2);
     return check_hip(hipGetLastError(), "cgnn_mlp_backward launch");
 }
@@ -352,10 +356,13 @@ int cgnn_mlp_backward(const cgnn_mlp* fwd, const cgnn_linear* fwd_part2, const c
     if (rc != CGNN_OK) return rc;
     rc = make_mlp_dev(bwd, &b, nullptr, "cgnn_mlp_backward(bwd)");
     if (rc != CGNN_OK) return rc;
-    if ((fwd->precision != CGNN_F32 && fwd->precision != CGNN_F32X3) || bwd->precision != fwd->precision) {
-        set_error("cgnn_mlp_backward: fwd and bwd weights must both be CGNN_F32 (exact) or both CGNN_F32X3");
+    const bool mixed = fwd->precision == CGNN_F16X2 && bwd->precision == CGNN_F32X3;
+    if (!mixed && ((fwd->precision != CGNN_F32 && fwd->precision != CGNN_F32X3) || bwd->precision != fwd->precision)) {
+        set_error("cgnn_mlp_backward: (fwd, bwd) weights must be (CGNN_F32, CGNN_F32), (CGNN_F32X3, CGNN_F32X3) or "
+                  "(CGNN_F16X2, CGNN_F32X3)");
         return CGNN_ERR_UNSUPPORTED;
     }
+    // (fwd_part2 / bwd_part2 carry no precision of their own: they must be packed like fwd / bwd)
     if (!u1 || !dy || !buf || n < 0 || f.nh != b.nh || !buf->g_o || (fwd_part2 != nullptr) != (bwd_part2 != nullptr) ||
         (fwd_part2 && !u2)) {
         set_error("cgnn_mlp_backward: invalid argument");
@@ -407,10 +414,12 @@ int cgnn_mlp_backward(const cgnn_mlp* fwd, const cgnn_linear* fwd_part2, const c
     const bool x3 = fwd->precision == CGNN_F32X3;
 #define CGNN_BWD(K1, K2, Hh, Oo)                                                                                        \
     if (K1T == K1 && K2T == K2 && HT == Hh && OT == Oo)                                                                  \
-        return x3 ? launch_bwd<CGNN_F32X3, K1, K2, Hh, Oo>(ln, f, b, fw2, bw2, u1, ld1, u2, ld2, dy, ld_dy, n, bb, du1,    \
-                                                          ld_du1, du2, ld_du2, st)                                       \
-                  : launch_bwd<CGNN_F32, K1, K2, Hh, Oo>(ln, f, b, fw2, bw2, u1, ld1, u2, ld2, dy, ld_dy, n, bb, du1,      \
-                                                        ld_du1, du2, ld_du2, st);
+        return mixed ? launch_bwd<CGNN_F16X2, CGNN_F32X3, K1, K2, Hh, Oo>(ln, f, b, fw2, bw2, u1, ld1, u2, ld2, dy, ld_dy, \
+                                                                         n, bb, du1, ld_du1, du2, ld_du2, st)            \
+               : x3  ? launch_bwd<CGNN_F32X3, CGNN_F32X3, K1, K2, Hh, Oo>(ln, f, b, fw2, bw2, u1, ld1, u2, ld2, dy, ld_dy, \
+                                                                         n, bb, du1, ld_du1, du2, ld_du2, st)            \
+                     : launch_bwd<CGNN_F32, CGNN_F32, K1, K2, Hh, Oo>(ln, f, b, fw2, bw2, u1, ld1, u2, ld2, dy, ld_dy, n,  \
+                                                                     bb, du1, ld_du1, du2, ld_du2, st);
     // square models hidden == latent in {32, 64, 128, 256}: node block (two inputs), encoder (narrow input), decoder
 #define CGNN_BWD_T(Tt) CGNN_BWD(Tt, Tt, Tt, Tt) CGNN_BWD(1, 0, Tt, Tt) CGNN_BWD(Tt, 0, Tt, 1)
     CGNN_BWD_T(1) CGNN_BWD_T(2) CGNN_BWD_T(4) CGNN_BWD_T(8)

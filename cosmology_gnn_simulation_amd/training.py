@@ -31,7 +31,7 @@ class _TrainMLP:
     ``module.parameters()`` order: (w, b) per Linear, then LayerNorm (weight, bias)."""
 
     def __init__(self, linears: Sequence[nn.Module], ln: Optional[nn.LayerNorm], split_at: Optional[int] = None,
-                 precision: str = "fp32"):
+                 precision: str = "fp32", latent_input: bool = False):
         if ops._prec(precision) not in (_lib.F32, _lib.F32X3):
             raise CgnnError(f"training arithmetic must be 'fp32' (exact) or 'fp32x3' (three bf16 terms), got {precision!r}")
         self.linears, self.ln = list(linears), ln
@@ -43,20 +43,24 @@ class _TrainMLP:
         self.in1 = int(split_at if split_at is not None else w0.shape[1])
         self.in2 = int(w0.shape[1] - self.in1)
         cols = (0, self.in1) if split_at is not None else None
-        self.fwd = ops.PackedMLP(wb, lnp, precision, first_layer_cols=cols)
-        self.fwd2 = ops.PackedLinear(w0, None, precision, self.in1, self.in2) if self.in2 else None
-        # The differentiable forward only has to hand f32-accurate activations to the backward (which recomputes its
-        # own from ``fwd``): under the emulated arithmetic it runs on the forward's fastest f32-accurate kernels, the
-        # two-fp16-term ones (latents behind a LayerNorm are O(1); the encoder, which sees raw features, and the
-        # gradients, which are tiny, never pass through them).
+        two_terms = ops._prec(precision) == _lib.F32X3 and latent_input       # see below
+        fwd_prec = "fp16x2" if two_terms else precision
+        self.fwd = ops.PackedMLP(wb, lnp, fwd_prec, first_layer_cols=cols)
+        self.fwd2 = ops.PackedLinear(w0, None, fwd_prec, self.in1, self.in2) if self.in2 else None
+        # Under the emulated arithmetic, MLPs fed by latents (processor rounds, decoders: values of O(1) behind a
+        # LayerNorm) take the two-fp16-term kernels wherever no gradient passes through the operands:
+        #   run / run2  the differentiable forward (it only hands f32-accurate latents to the backward): the 16-row
+        #               ring kernel for square layers up to 128, else the 32-row packing;
+        #   rec / rec2  the forward that cgnn_mlp_backward recomputes (it takes (fp16x2, fp32x3) pairs).
+        # The encoder sees raw features and every gradient can be 1e-8: those stay on three bf16 terms (f32 range).
         self.run, self.run2 = self.fwd, self.fwd2
-        if ops._prec(precision) == _lib.F32X3:
+        self.rec, self.rec2 = self.fwd, self.fwd2
+        if two_terms:
             square = self.in2 == self.in1 == int(w0.shape[0]) and self.in1 in (32, 64, 128) and ln is not None and \
                 all(int(l.weight.shape[0]) == self.in1 == int(l.weight.shape[1]) for l in linears[1:])
-            fast = "fp16x2_n16" if square else "fp16x2"
-            if square or self.in2 == 0:
-                self.run = ops.PackedMLP(wb, lnp, fast, first_layer_cols=cols)
-                self.run2 = ops.PackedLinear(w0, None, fast, self.in1, self.in2) if self.in2 else None
+            if square:
+                self.run = ops.PackedMLP(wb, lnp, "fp16x2_n16", first_layer_cols=cols)
+                self.run2 = ops.PackedLinear(w0, None, "fp16x2_n16", self.in1, self.in2)
         t = lambda w: w.detach().t().contiguous()  # noqa: E731
         tw = [(t(w0[:, :self.in1]), None)] + [(t(l.weight), None) for l in linears[1:]]
         self.bwd = ops.PackedMLP(tw, None, precision)
@@ -79,7 +83,7 @@ class _TrainMLP:
         """-> (du1, du2, [parameter gradients in ``params()`` order])."""
         n = u1.shape[0]
         dy = dy.contiguous()
-        du1, du2 = ops.mlp_backward(self.fwd, self.fwd2, self.bwd, self.bwd2, u1, u2, dy, scratch, want_du1, want_du2)
+        du1, du2 = ops.mlp_backward(self.rec, self.rec2, self.bwd, self.bwd2, u1, u2, dy, scratch, want_du1, want_du2)
         grads: List[torch.Tensor] = []
         H = self.hidden
         for l, lin in enumerate(self.linears):
@@ -114,9 +118,10 @@ class TrainPacks:
         prec = getattr(model, "train_precision", "fp32")
         self.precision = prec
         self.enc = _TrainMLP(*_split_mlp(model.encoder.node_model), precision=prec)
-        self.rounds = [_TrainMLP(*_split_mlp(net.node_model), split_at=D, precision=prec) for net in model.processor]
-        self.dec_acc = _TrainMLP(*_split_mlp(model.decoder_acc), precision=prec)
-        self.dec_tr = _TrainMLP(*_split_mlp(model.decoder_temp_rate), precision=prec)
+        self.rounds = [_TrainMLP(*_split_mlp(net.node_model), split_at=D, precision=prec, latent_input=True)
+                       for net in model.processor]
+        self.dec_acc = _TrainMLP(*_split_mlp(model.decoder_acc), precision=prec, latent_input=True)
+        self.dec_tr = _TrainMLP(*_split_mlp(model.decoder_temp_rate), precision=prec, latent_input=True)
         self.all = [self.enc] + self.rounds + [self.dec_acc, self.dec_tr]
         for m in self.all:
             if m.hidden != D or m.hidden not in (32, 64, 128, 256):

@@ -257,7 +257,7 @@ int cgnn_edge_stream_run(const void* image, size_t image_bytes, int32_t latent, 
 /* ---- backward of a row-wise MLP (+LayerNorm): the node stream of train.py:263 ------------------------
  * In reference-faithful mode only the node path carries gradient (the edge models' parameters get
  * none), so training needs the backward of cgnn_mlp_rows / cgnn_node_block and the transpose of the
- * aggregation (= cgnn_aggregate with src and dst swapped, general path).  Exact f32 (CGNN_F32) only.
+ * aggregation (= cgnn_aggregate with src and dst swapped, general path).
  *
  * cgnn_mlp_backward recomputes the forward of one 32-row tile from its inputs (no activations are kept from the
  * forward pass), then walks the chain backwards:
@@ -272,7 +272,11 @@ int cgnn_edge_stream_run(const void* image, size_t image_bytes, int32_t latent, 
  *   dW_nh = g_o^T h[nh-1], dW_l = g_a[l]^T h[l-1], dW_0a = g_a[0]^T u1, dW_0b = g_a[0]^T u2, db = column sums,
  *   dgamma = colsum(dy * zhat), dbeta = colsum(dy).
  * `fwd` holds the forward weights (layer[0] = W_0a; fwd_part2 = W_0b or NULL), `bwd` the TRANSPOSED weights
- * packed the same way (bwd->layer[l] = W_l^T, in_dim = out_l, out_dim = in_l; bwd_part2 = W_0b^T or NULL). */
+ * packed the same way (bwd->layer[l] = W_l^T, in_dim = out_l, out_dim = in_l; bwd_part2 = W_0b^T or NULL).
+ * Arithmetic by (fwd->precision, bwd->precision): (CGNN_F32, CGNN_F32) exact; (CGNN_F32X3, CGNN_F32X3) three bf16 terms;
+ * (CGNN_F16X2, CGNN_F32X3) recomputes the forward on two fp16 terms (inputs must respect its range: latents, not raw
+ * features) and runs the gradient chain, whose values can be far below fp16's range, on three bf16 terms.
+ * fwd_part2 / bwd_part2 are packed like fwd / bwd. */
 typedef struct {
     float* h[CGNN_MAX_HIDDEN_LAYERS];
     float* g_a[CGNN_MAX_HIDDEN_LAYERS];

@@ -6,7 +6,7 @@ Tolerance: gradients are float32 sums over all particles in a different order th
 import pytest
 import torch
 
-from cosmology_gnn_simulation_amd import data_utils, graph_network, losses, ops, synthetic
+from cosmology_gnn_simulation_amd import _lib, data_utils, graph_network, losses, ops, synthetic
 from cosmology_gnn_simulation_amd.graph import Batch, Data
 from oracle import cpu_ref
 
@@ -46,9 +46,14 @@ class _Lin:   # what training._TrainMLP needs from an nn.Linear / nn.LayerNorm
     (257, 128, 0, 128, 3, 2, False), (64, 64, 0, 64, 1, 3, False), (4100, 128, 128, 128, 128, 2, True),
     (95, 32, 32, 32, 32, 1, True), (700, 64, 64, 64, 64, 3, True),
     (200, 17, 0, 256, 256, 2, True), (300, 256, 256, 256, 256, 2, True), (150, 256, 0, 256, 3, 2, False)])   # latent 256 (cfg5)
-@pytest.mark.parametrize("precision", ["fp32", "fp32x3"])
+@pytest.mark.parametrize("precision", ["fp32", "fp32x3", "fp32x3 with the forward recomputed on fp16x2"])
 def test_mlp_backward_matches_autograd(n, fin, fin2, hid, out, nh, ln, precision):
+    """cgnn_mlp_backward + the parameter-gradient reductions of one MLP against torch autograd on the oracle: exact f32,
+    three bf16 terms, and the pairing the processor rounds / decoders train with (recomputed forward on two fp16 terms,
+    gradient chain on three bf16 terms)."""
     from cosmology_gnn_simulation_amd.training import _TrainMLP
+    latent_input = precision.endswith("fp16x2")
+    precision = precision.split()[0]
     gen = torch.Generator().manual_seed(n + fin + out)
     sd = {k: v.requires_grad_(True) for k, v in _rand_mlp(gen, fin + fin2, hid, out, nh, ln).items()}
     u = torch.randn(n, fin + fin2, generator=gen).requires_grad_(True)
@@ -59,7 +64,8 @@ def test_mlp_backward_matches_autograd(n, fin, fin2, hid, out, nh, ln, precision
     lins = [_Lin(sd[f"m.0.{2 * i}.weight"].detach().to(DEV), sd[f"m.0.{2 * i}.bias"].detach().to(DEV))
             for i in range(nh + 1)]
     lnm = _Lin(sd["m.1.weight"].detach().to(DEV), sd["m.1.bias"].detach().to(DEV)) if ln else None
-    tm = _TrainMLP(lins, lnm, split_at=fin if fin2 else None, precision=precision)
+    tm = _TrainMLP(lins, lnm, split_at=fin if fin2 else None, precision=precision, latent_input=latent_input)
+    assert (tm.rec.precision == _lib.F16X2) == latent_input
     scratch = ops.BackwardScratch(n, hid, max(hid, 32), nh, DEV)
     ud = u.detach().to(DEV)
     u1 = ud[:, :fin].contiguous()
