@@ -181,3 +181,33 @@ def test_project_nodes_fp16x2_writes_f32_tables(d, h):
     with pytest.raises(_lib.CgnnError):
         ops.project_nodes(ops.PackedLinear(w, None, "fp16x2", 0, d), ops.PackedLinear(w, b, "fp16x2", d, d), x,
                           p_format=_lib.P_BF16_S32)
+
+
+@pytest.mark.parametrize("nh", [1, 3, 4])
+def test_mlp_rows_fp16x2_depths_and_loud_overflow(nh):
+    """The 32-row two-fp16-term packing through cgnn_mlp_rows at other depths, and its range contract: an input of
+    7e4 (beyond fp16) turns its row non-finite instead of producing a wrong finite number; other rows are untouched."""
+    n, d = 500, 128
+    gen = torch.Generator().manual_seed(nh)
+    dims = [d] + [d] * nh + [3]
+    lin = []
+    for i in range(nh + 1):
+        bound = 1.0 / np.sqrt(dims[i])
+        lin.append((((torch.rand(dims[i + 1], dims[i], generator=gen) * 2 - 1) * bound).to(DEV),
+                    ((torch.rand(dims[i + 1], generator=gen) * 2 - 1) * bound).to(DEV)))
+    x = torch.randn(n, d, generator=gen).to(DEV) * 3
+    h = x.double()
+    for i, (w, b) in enumerate(lin):
+        h = h @ w.double().t() + b.double()
+        if i < nh:
+            h = torch.relu(h)
+    got = ops.mlp_rows(ops.PackedMLP(lin, None, "fp16x2"), x)
+    assert float((got.double() - h).abs().max()) <= 2e-6 * float(h.abs().max())
+    x[7, 5] = 7.0e4
+    bad = ops.mlp_rows(ops.PackedMLP(lin, None, "fp16x2"), x)
+    assert not torch.isfinite(bad[7]).any()
+    keep = torch.ones(n, dtype=torch.bool, device=DEV)
+    keep[7] = False
+    assert torch.equal(bad[keep], got[keep])
+    ok = ops.mlp_rows(ops.PackedMLP(lin, None, "fp32x3"), x)          # three bf16 terms have the f32 range
+    assert torch.isfinite(ok).all()

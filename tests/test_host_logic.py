@@ -211,3 +211,21 @@ def test_asm_hazard_scanner_sees_a_short_gap(tmp_path):
     padded.write_text(body % 3)
     assert len(scan_asm_hazards.scan(str(short))) == 2          # s4 after 4 states, s5 after 3
     assert scan_asm_hazards.scan(str(padded)) == []
+
+
+def test_committed_pmc_traffic_belongs_to_the_committed_kernels():
+    """profiles/traffic.json is keyed by a hash of each kernel's sources (bench.kernel_source_sha16); bench.py drops an
+    entry whose kernel changed since the PMC pass.  At a commit the entries of the headline configuration should be live:
+    a kernel edit after the last profile round shows up here, not as a silent `traffic: null` in the bench line."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    try:
+        import bench
+    finally:
+        sys.path.pop(0)
+    db = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    stale = [k for k, v in db.items() if isinstance(v, dict) and bench.kernel_source_sha16(v["source"]) != v["source_sha16"]]
+    assert not stale, f"re-run scripts/profile_round.sh: PMC traffic entries measured on older kernel sources: {stale}"
+    for key in ("edge_stream+enc:1000000:16:128:10", "node_block:1000000:128", "aggregate:1000000:16:128"):
+        assert bench._traffic(key, "") and bench._traffic(key, "") > 0, key
