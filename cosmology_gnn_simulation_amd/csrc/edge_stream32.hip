@@ -108,12 +108,23 @@ struct Ring32 {
         if (primed) return;
 #endif
         const unsigned off = (unsigned)(wave + CGNN_S32_WAVES * i) * 1024u;
-        // (a scalar-base form of the instruction -- s_mov m0 + global_load_lds with an SGPR base and one constant lane
-        // offset, no vector add per piece -- measured 0.1-0.5 ms SLOWER here: its asm statement is a scheduling fence)
-        const char* src = image + (size_t)dma_chunk * G::STRIDE + off + lane * 16;
         char* dst = cgnn_smem + (unsigned)dma_slot * G::STRIDE + off;
         asm volatile("" ::: "memory");
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CGNN_S32_GLOBAL_DMA)
+        // Buffer form of the LDS-DMA instruction (buffer_load_dwordx4 ... offen lds): descriptor of the image + the
+        // piece's byte offset as a SCALAR + one constant lane offset, so a piece costs no vector instruction.  The
+        // global form needs a 64-bit vector add per piece (27 pieces per pass): 0.3 ms of this kernel (A/B on one box:
+        // 20.71 -> 20.39 ms).  An earlier attempt at a scalar base through inline asm (s_mov m0 + global_load_lds with an
+        // SGPR pair) was 0.1-0.5 ms SLOWER: an asm statement fences the scheduler, this builtin does not.
+        // (CGNN_S32_GLOBAL_DMA keeps the old form for A/B timing; the host pass of hipcc does not know the buffer builtin.)
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(image), 0, (int)((unsigned)count * G::STRIDE), 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsVoidPtrG)dst, 16, (unsigned)lane * 16u,
+                                                 (unsigned)dma_chunk * G::STRIDE + off, 0, 0);
+#else
+        const char* src = image + (size_t)dma_chunk * G::STRIDE + off + lane * 16;
         __builtin_amdgcn_global_load_lds((GlobalVoidPtrG)src, (LdsVoidPtrG)dst, 16, 0, 0);
+#endif
         asm volatile("" ::: "memory");
     }
     __device__ __forceinline__ void dma_done() {
