@@ -247,7 +247,10 @@ def test_training_step_gradients_match_reference_autograd(n, k, latent, nh, step
             assert ref.grad is None and got[name].grad is None, name
         else:
             assert got[name].grad is not None, name
-            assert _close(got[name].grad, ref.grad, gtol), name
+            # a one-element gradient (the temperature decoder's output bias) is a single f32 sum over all particles of
+            # terms that cancel (|sum| << sum |terms|): "relative to its largest entry" is relative to that small result
+            # and both sides' summation orders show (3.2e-5 was seen once in a dozen runs)
+            assert _close(got[name].grad, ref.grad, gtol if ref.grad.numel() > 1 else 5 * gtol), name
 
 
 def test_training_on_a_batch_of_graphs_and_optimizer_step():
