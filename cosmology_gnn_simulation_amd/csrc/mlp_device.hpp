@@ -134,6 +134,25 @@ struct WSel<CGNN_BF16, true> {
     }
 };
 
+// two-part (CGNN_F16X2) fragments resident in LDS: [m][part][lane][8 fp16]
+struct LdsWf2g {
+    LdsWeightPtr p;
+    __device__ __forceinline__ explicit LdsWf2g(LdsWeightPtr q) : p(q) {}
+    __device__ __forceinline__ f16x8x2 fetch(int m, int lane) const {
+        f16x8x2 r;
+        r.p[0] = __builtin_bit_cast(f16x8, p[(m * 2) * 64 + lane]);
+        r.p[1] = __builtin_bit_cast(f16x8, p[(m * 2 + 1) * 64 + lane]);
+        return r;
+    }
+};
+template <>
+struct WSel<CGNN_F16X2, true> {
+    typedef LdsWf2g type;
+    static __device__ __forceinline__ type get(const MlpDev& m, int l) {
+        return LdsWf2g((LdsWeightPtr)(cgnn_smem + m.lds_off[l]));
+    }
+};
+
 // Writers of the three cgnn_ptable formats from the 32-row act layout.
 template <int PFMT>
 struct PFmt;

@@ -106,9 +106,11 @@ static int launch_mlp_rows(const MlpDev& m, size_t lds, const float* x, int64_t 
 template <int PREC, int K0T, int HT, int OT>
 static int dispatch_lds(const MlpDev& m, size_t lds, const float* x, int64_t n, int ld_x, float* y, int ld_y,
                         int y_tiled, hipStream_t st) {
-    if (PREC == CGNN_BF16 && HT <= 4 && OT <= 4 && K0T <= 4 && lds <= CGNN_LDS_WEIGHT_BUDGET && n >= 4096)
-        return launch_mlp_rows<PREC, (PREC == CGNN_BF16 && HT <= 4 && OT <= 4 && K0T <= 4), K0T, HT, OT>(
-            m, lds, x, n, ld_x, y, ld_y, y_tiled, st);
+    // weights resident in LDS when they fit (bf16 up to 128 wide; two fp16 terms, 64 KiB per 128 x 128 layer, with up to
+    // two hidden layers): read from L2 by every wave they were 10 TB/s of L2 traffic for the decoders at 1 M rows
+    constexpr bool CAN = (PREC == CGNN_BF16 || PREC == CGNN_F16X2) && HT <= 4 && OT <= 4 && K0T <= 4;
+    if (CAN && lds <= CGNN_LDS_WEIGHT_BUDGET && n >= 4096)
+        return launch_mlp_rows<PREC, CAN, K0T, HT, OT>(m, lds, x, n, ld_x, y, ld_y, y_tiled, st);
     return launch_mlp_rows<PREC, false, K0T, HT, OT>(m, lds, x, n, ld_x, y, ld_y, y_tiled, st);
 }
 

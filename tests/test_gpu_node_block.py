@@ -211,3 +211,31 @@ def test_mlp_rows_fp16x2_depths_and_loud_overflow(nh):
     assert torch.equal(bad[keep], got[keep])
     ok = ops.mlp_rows(ops.PackedMLP(lin, None, "fp32x3"), x)          # three bf16 terms have the f32 range
     assert torch.isfinite(ok).all()
+
+
+@pytest.mark.parametrize("fin,d,out,ln", [(17, 128, 128, True), (128, 128, 3, False), (4, 64, 64, True), (64, 64, 1, False)])
+def test_mlp_rows_fp16x2_with_weights_resident_in_lds(fin, d, out, ln):
+    """From 4096 rows on cgnn_mlp_rows keeps two-fp16-term weights of up to 128-wide layers in LDS (encoder and decoder
+    shapes): same results as below that size (weights read through L2) bit for bit, f32 rounding level against float64."""
+    n, nh = 6000, 2
+    gen = torch.Generator().manual_seed(fin + out)
+    dims = [fin] + [d] * nh + [out]
+    lin = []
+    for i in range(nh + 1):
+        bound = 1.0 / np.sqrt(dims[i])
+        lin.append((((torch.rand(dims[i + 1], dims[i], generator=gen) * 2 - 1) * bound).to(DEV),
+                    ((torch.rand(dims[i + 1], generator=gen) * 2 - 1) * bound).to(DEV)))
+    lnp = ((1 + 0.1 * torch.randn(out, generator=gen)).to(DEV), (0.1 * torch.randn(out, generator=gen)).to(DEV)) if ln else None
+    x = torch.randn(n, fin, generator=gen).to(DEV) * 2
+    h = x.double()
+    for i, (w, b) in enumerate(lin):
+        h = h @ w.double().t() + b.double()
+        if i < nh:
+            h = torch.relu(h)
+    if ln:
+        h = F.layer_norm(h, (out,), lnp[0].double(), lnp[1].double(), 1e-5)
+    mlp = ops.PackedMLP(lin, lnp, "fp16x2")
+    got = ops.mlp_rows(mlp, x)
+    assert float((got.double() - h).abs().max()) <= 2e-6 * float(h.abs().max())
+    small = torch.cat([ops.mlp_rows(mlp, x[i:i + 2000].contiguous()) for i in range(0, n, 2000)])     # < 4096 rows: weights from L2
+    assert torch.equal(got, small)
