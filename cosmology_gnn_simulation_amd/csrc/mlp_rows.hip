@@ -51,7 +51,29 @@ __global__ __launch_bounds__(CGNN_BLOCK) void mlp_rows_kernel(MlpDev m, const fl
     }
 }
 
-template <int PREC, int PFMT, int DT, int HT>
+// weight sources of the projection kernel: global (buffer loads, every wave streams both matrices from L2 per tile) or,
+// WLDS, both matrices copied into LDS once per workgroup (bf16: 2 x 32 KiB at 128 x 128, two fp16 terms: 2 x 64 KiB)
+template <int PREC, bool WLDS>
+struct ProjW {
+    typedef BufW<PREC> type;
+    static __device__ __forceinline__ type get(const void* w, unsigned bytes, int) { return type(w, bytes); }
+};
+template <>
+struct ProjW<CGNN_BF16, true> {
+    typedef LdsW type;
+    static __device__ __forceinline__ type get(const void*, unsigned bytes, int which) {
+        return LdsW((LdsWeightPtr)(cgnn_smem + which * bytes));
+    }
+};
+template <>
+struct ProjW<CGNN_F16X2, true> {
+    typedef LdsWf2g type;
+    static __device__ __forceinline__ type get(const void*, unsigned bytes, int which) {
+        return LdsWf2g((LdsWeightPtr)(cgnn_smem + which * bytes));
+    }
+};
+
+template <int PREC, int PFMT, int DT, int HT, bool WLDS = false>
 __global__ __launch_bounds__(CGNN_BLOCK) void project_kernel(const void* ws, const void* wd, const float* __restrict__ bd,
                                                              int hidden, const float* __restrict__ x, int64_t n,
                                                              typename PFmt<PFMT>::elem* __restrict__ ps,
@@ -59,7 +81,19 @@ __global__ __launch_bounds__(CGNN_BLOCK) void project_kernel(const void* ws, con
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int64_t tiles = (n + 31) / 32;
     constexpr unsigned wbytes = DT * HT * 1024 * (PREC == CGNN_BF16 ? 2 : (PREC == CGNN_F32X3 ? 6 : 4));
-    const BufW<PREC> wsrc_s(ws, wbytes), wsrc_d(wd, wbytes);
+    if (WLDS) {
+        typedef unsigned int u32x4p __attribute__((ext_vector_type(4)));
+        u32x4p* dst = reinterpret_cast<u32x4p*>(cgnn_smem);
+        const u32x4p* s0 = reinterpret_cast<const u32x4p*>(ws);
+        const u32x4p* s1 = reinterpret_cast<const u32x4p*>(wd);
+        for (unsigned i = threadIdx.x; i < wbytes / 16; i += blockDim.x) {
+            if (ws != nullptr) dst[i] = s0[i];
+            if (wd != nullptr) dst[wbytes / 16 + i] = s1[i];
+        }
+        __syncthreads();
+    }
+    const typename ProjW<PREC, WLDS>::type wsrc_s = ProjW<PREC, WLDS>::get(ws, wbytes, 0);
+    const typename ProjW<PREC, WLDS>::type wsrc_d = ProjW<PREC, WLDS>::get(wd, wbytes, 1);
     const TileRange tr = tile_range(tiles);
     for (int64_t tile = tr.first; tile < tr.end; tile += tr.stride) {
         const int64_t row = tile * 32 + r;
@@ -83,6 +117,30 @@ __global__ __launch_bounds__(CGNN_BLOCK) void project_kernel(const void* ws, con
             if (row < n) PFmt<PFMT>::template store<HT>(acc, pd, row, h);
         }
     }
+}
+
+// both projection matrices resident in LDS when they fit and there are enough rows to pay for the copy (per workgroup)
+template <int PREC, int PFMT, int DT, int HT>
+static int launch_project(const void* ws, const void* wd, const float* bd, int hidden, const float* x, int64_t n,
+                          void* ps, void* pd, hipStream_t st) {
+    typedef typename PFmt<PFMT>::elem E;
+    constexpr unsigned wbytes = DT * HT * 1024 * (PREC == CGNN_BF16 ? 2 : (PREC == CGNN_F32X3 ? 6 : 4));
+    constexpr bool CAN = (PREC == CGNN_BF16 || PREC == CGNN_F16X2) && 2 * wbytes <= CGNN_LDS_WEIGHT_BUDGET;
+    if (CAN && n >= 4096) {
+        auto kern = project_kernel<PREC, PFMT, DT, HT, CAN>;
+        if (2 * wbytes > 48 * 1024) {
+            int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * wbytes)),
+                               "hipFuncSetAttribute(project)");
+            if (rc != CGNN_OK) return rc;
+        }
+        const int grid = grid_for_tiles((n + 31) / 32, 2 * wbytes > 76 * 1024 ? 1 : 2);
+        kern<<<grid, CGNN_BLOCK, 2 * wbytes, st>>>(ws, wd, bd, hidden, x, n, (E*)ps, (E*)pd);
+    } else {
+        project_kernel<PREC, PFMT, DT, HT, false><<<grid_for_tiles((n + 31) / 32), CGNN_BLOCK, 0, st>>>(
+            ws, wd, bd, hidden, x, n, (E*)ps, (E*)pd);
+    }
+    return check_hip(hipGetLastError(), "cgnn_project_nodes launch");
 }
 
 int mlp_rows_n16_encoder(const MlpDev& m, size_t lds, const float* x, int64_t n, int ld_x, float* y,
@@ -218,7 +276,6 @@ int cgnn_project_nodes(const cgnn_linear* ws, const cgnn_linear* wd, int32_t pre
     if (n == 0) return CGNN_OK;
     hipStream_t st = (hipStream_t)stream;
     const int DT = D / 32, HT = H / 32;
-    const int grid = grid_for_tiles((n + 31) / 32);
     const void* wsp = ps ? ws->w : nullptr;
     const void* wdp = pd ? wd->w : nullptr;
     const float* bd = pd ? wd->b : nullptr;
@@ -231,18 +288,12 @@ int cgnn_project_nodes(const cgnn_linear* ws, const cgnn_linear* wd, int32_t pre
 #define CGNN_PAIR(Hh, Dd)                                                                                          \
     if (HT == Hh && DT == Dd) {                                                                                     \
         if (p_format == CGNN_P_F32 && precision == CGNN_F16X2)                                                      \
-            project_kernel<CGNN_F16X2, CGNN_P_F32, Dd, Hh><<<grid, CGNN_BLOCK, 0, st>>>(wsp, wdp, bd, H, x, n,       \
-                                                                                       (float*)ps, (float*)pd);    \
-        else if (p_format == CGNN_P_F32)                                                                            \
-            project_kernel<CGNN_F32, CGNN_P_F32, Dd, Hh><<<grid, CGNN_BLOCK, 0, st>>>(wsp, wdp, bd, H, x, n,         \
-                                                                                     (float*)ps, (float*)pd);      \
-        else if (p_format == CGNN_P_BF16_S32)                                                                       \
-            project_kernel<CGNN_BF16, CGNN_P_BF16_S32, Dd, Hh><<<grid, CGNN_BLOCK, 0, st>>>(                         \
-                wsp, wdp, bd, H, x, n, (__bf16*)ps, (__bf16*)pd);                                                   \
-        else                                                                                                        \
-            project_kernel<CGNN_BF16, CGNN_P_BF16_S16, Dd, Hh><<<grid, CGNN_BLOCK, 0, st>>>(                         \
-                wsp, wdp, bd, H, x, n, (__bf16*)ps, (__bf16*)pd);                                                   \
-        return check_hip(hipGetLastError(), "cgnn_project_nodes launch");                                           \
+            return launch_project<CGNN_F16X2, CGNN_P_F32, Dd, Hh>(wsp, wdp, bd, H, x, n, ps, pd, st);                \
+        if (p_format == CGNN_P_F32)                                                                                 \
+            return launch_project<CGNN_F32, CGNN_P_F32, Dd, Hh>(wsp, wdp, bd, H, x, n, ps, pd, st);                  \
+        if (p_format == CGNN_P_BF16_S32)                                                                            \
+            return launch_project<CGNN_BF16, CGNN_P_BF16_S32, Dd, Hh>(wsp, wdp, bd, H, x, n, ps, pd, st);            \
+        return launch_project<CGNN_BF16, CGNN_P_BF16_S16, Dd, Hh>(wsp, wdp, bd, H, x, n, ps, pd, st);               \
     }
     CGNN_FOR_EACH_PAIR(CGNN_PAIR)
 #undef CGNN_PAIR

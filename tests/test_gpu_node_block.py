@@ -239,3 +239,21 @@ def test_mlp_rows_fp16x2_with_weights_resident_in_lds(fin, d, out, ln):
     assert float((got.double() - h).abs().max()) <= 2e-6 * float(h.abs().max())
     small = torch.cat([ops.mlp_rows(mlp, x[i:i + 2000].contiguous()) for i in range(0, n, 2000)])     # < 4096 rows: weights from L2
     assert torch.equal(got, small)
+
+
+@pytest.mark.parametrize("prec,d,fmt", [("bf16", 128, None), ("bf16", 64, None), ("fp16x2", 128, None), ("fp16x2", 32, None),
+                                         ("bf16", 128, _lib.P_BF16_S16)])
+def test_project_nodes_with_weights_resident_in_lds(prec, d, fmt):
+    """From 4096 rows on cgnn_project_nodes copies both matrices into LDS once per workgroup (bf16 / two fp16 terms up to
+    128 x 128): the tables equal those of the global-weight path (calls below that size) bit for bit."""
+    n = 9000
+    gen = torch.Generator().manual_seed(d)
+    w = ((torch.rand(d, 3 * d, generator=gen) * 2 - 1) / np.sqrt(3 * d)).to(DEV)
+    b = ((torch.rand(d, generator=gen) * 2 - 1) / np.sqrt(3 * d)).to(DEV)
+    x = (torch.randn(n, d, generator=gen) * 3).to(DEV)
+    ws, wd = ops.PackedLinear(w, None, prec, 0, d), ops.PackedLinear(w, b, prec, d, d)
+    ps, pd = ops.project_nodes(ws, wd, x, p_format=fmt)
+    parts = [ops.project_nodes(ws, wd, x[i:i + 3000].contiguous(), p_format=fmt) for i in range(0, n, 3000)]
+    assert torch.equal(ps, torch.cat([p[0] for p in parts])) and torch.equal(pd, torch.cat([p[1] for p in parts]))
+    only_d = ops.project_nodes(None, wd, x, p_format=fmt)[1]        # one table alone (ghost rows take this form)
+    assert torch.equal(only_d, pd)
