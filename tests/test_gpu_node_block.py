@@ -135,7 +135,8 @@ def test_node_block_fused_projection_epilogue(fmt, p_format):
         assert float((diff > 0).float().mean()) < 0.02
 
 
-@pytest.mark.parametrize("n,d,h,nh", [(1000, 256, 256, 2), (333, 64, 128, 2), (70, 256, 128, 1), (2000, 128, 128, 2)])
+@pytest.mark.parametrize("n,d,h,nh", [(1000, 256, 256, 2), (333, 64, 128, 2), (70, 256, 128, 1), (2000, 128, 128, 2),
+                                      (5000, 256, 256, 2), (2100, 256, 256, 3), (4133, 256, 256, 1)])
 def test_node_block_fp16x2_32_row_packing(n, d, h, nh):
     """CGNN_F16X2 (the two-fp16-term arithmetic in the 32-row packing, any supported latent / hidden pair): f32 rounding
     level against float64, like the three-bf16-term form it replaces at half the matrix work."""
