@@ -141,8 +141,10 @@ int cgnn_relayout(const float* src, int32_t from, float* dst, int32_t to, int64_
  * ps[n,H] = x[n,D] * Ws^T ; pd[n,H] = x[n,D] * Wd^T + b1, where [Ws|Wd|We] is the
  * column split of the edge model's first Linear (reference graph_network.py:89-90:
  * cat([x[src], x[dest], edge_attr])).  Either output may be NULL.
- * `precision` is the packing of ws/wd (CGNN_F32 or CGNN_BF16); `p_format` (cgnn_ptable)
- * the layout of the tables, which must be the one the consuming cgnn_edge_block expects. */
+ * `precision` is the packing of ws/wd: CGNN_F32 or CGNN_F16X2 (both write CGNN_P_F32 tables) or CGNN_BF16 (either
+ * bf16 table order); `p_format` (cgnn_ptable) the layout of the tables, which must be the one the consuming
+ * cgnn_edge_block expects.  From 4096 rows on, bf16 / two-fp16-term matrices of up to 128 x 128 are copied into LDS once
+ * per workgroup instead of being streamed from L2 by every wave (same results bit for bit). */
 int cgnn_project_nodes(const cgnn_linear* ws, const cgnn_linear* wd, int32_t precision,
                        const float* x, int64_t n, void* ps, void* pd, int32_t p_format, void* stream);
 
