@@ -36,7 +36,7 @@ EXPORTS = (
     "cgnn_gather_rows", "cgnn_scatter_rows", "cgnn_tiled_rows", "cgnn_relayout", "cgnn_window_features",
     "cgnn_mlp_backward", "cgnn_weight_grad", "cgnn_weight_grad_x3_workspace_bytes", "cgnn_weight_grad_x3",
     "cgnn_col_dot", "cgnn_col_dot2", "cgnn_csr_workspace_bytes", "cgnn_csr_build",
-    "cgnn_aggregate_csr", "cgnn_edge_stream", "cgnn_edge_stream_image_bytes", "cgnn_edge_stream_image_build",
+    "cgnn_aggregate_csr", "cgnn_aggregate_csr_add", "cgnn_edge_stream", "cgnn_edge_stream_image_bytes", "cgnn_edge_stream_image_build",
     "cgnn_edge_stream_run", "cgnn_aggregate_plan_bytes", "cgnn_aggregate_plan_build", "cgnn_aggregate_planned",
 )
 ROWS, TILED32 = 0, 1
@@ -115,6 +115,7 @@ def load() -> C.CDLL:
     lib.cgnn_csr_workspace_bytes.argtypes = [i64]
     lib.cgnn_csr_build.argtypes = [vp, vp, i64, i64, vp, vp, vp, sz, vp]
     lib.cgnn_aggregate_csr.argtypes = [vp, vp, vp, i64, i32, vp, vp]
+    lib.cgnn_aggregate_csr_add.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp, vp]
     lib.cgnn_weight_grad_x3_workspace_bytes.argtypes = []
     lib.cgnn_weight_grad_x3_workspace_bytes.restype = C.c_size_t
     lib.cgnn_weight_grad_x3.argtypes = [vp, i32, vp, i32, i64, vp, i32, i32, vp, vp, C.c_size_t, vp]

@@ -722,15 +722,21 @@ class SenderCsr:
                                      self.col.data_ptr(), ws.data_ptr(), nbytes, stream_ptr(key.device)), "cgnn_csr_build")
 
 
-def aggregate_csr(table: torch.Tensor, csr: SenderCsr, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``out[r] = sum_{p in row r} table[csr.col[p]]``."""
+def aggregate_csr(table: torch.Tensor, csr: SenderCsr, out: Optional[torch.Tensor] = None,
+                  add1: Optional[torch.Tensor] = None, add2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``out[r] = (add1[r] + add2[r] +) sum_{p in row r} table[csr.col[p]]``; ``out`` may be ``add1`` or ``add2``."""
     table = f32c(table, "table")
+    shape = (csr.rows, table.shape[1])
     if out is None:
-        out = torch.empty((csr.rows, table.shape[1]), dtype=torch.float32, device=table.device)
+        out = torch.empty(shape, dtype=torch.float32, device=table.device)
+    for t, name in ((add1, "add1"), (add2, "add2"), (out, "out")):
+        if t is not None and (tuple(t.shape) != shape or t.dtype != torch.float32 or not t.is_contiguous()
+                              or t.device != table.device):
+            raise CgnnError(f"aggregate_csr: {name} must be contiguous float32 {shape} on the table's device")
     with _timed("aggregate_csr", table.device):
-        check(_lib.load().cgnn_aggregate_csr(table.data_ptr(), csr.row_ptr.data_ptr(), csr.col.data_ptr(), csr.rows,
-                                             table.shape[1], out.data_ptr(), stream_ptr(table.device)),
-              "cgnn_aggregate_csr")
+        check(_lib.load().cgnn_aggregate_csr_add(table.data_ptr(), csr.row_ptr.data_ptr(), csr.col.data_ptr(), csr.rows,
+                                                 table.shape[1], ptr(add1), ptr(add2), out.data_ptr(),
+                                                 stream_ptr(table.device)), "cgnn_aggregate_csr_add")
     return out
 
 

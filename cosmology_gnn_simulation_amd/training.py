@@ -176,8 +176,7 @@ class _NodeStream(torch.autograd.Function):
             ctx.aggs[i] = None
             du1, du2, grads_of[id(r)] = r.backward(x, agg, dx, scratch, True, True)
             # x_{i+1} = x_i + f(x_i, agg(x_i)):  dx_i = dx_{i+1} + du1 + A^T du2     (A^T: senders <- receivers)
-            dagg = ops.aggregate_csr(du2, by_sender)
-            dx = dx.add_(du1).add_(dagg)
+            dx = ops.aggregate_csr(du2, by_sender, out=dx, add1=dx, add2=du1)      # one pass instead of three
         need_dx0 = ctx.needs_input_grad[2]
         dx0, _, grads_of[id(packs.enc)] = packs.enc.backward(x0, None, dx, scratch, need_dx0)
         flat = [g for m in packs.all for g in grads_of[id(m)]]

@@ -328,6 +328,11 @@ int cgnn_csr_build(const int32_t* key, const int32_t* val, int64_t num_edges, in
                    int32_t* col, void* workspace, size_t workspace_bytes, void* stream);
 int cgnn_aggregate_csr(const float* table, const int32_t* row_ptr, const int32_t* col, int64_t num_rows, int32_t width,
                        float* out, void* stream);
+/* The same sum plus up to two row-aligned addends (either may be NULL):
+ *   out[r] = add1[r] + add2[r] + sum_{p in row r} table[col[p]]
+ * -- the backward of a residual round, dx_i = dx_{i+1} + du1 + A^T du2, in one pass.  out may alias add1 or add2. */
+int cgnn_aggregate_csr_add(const float* table, const int32_t* row_ptr, const int32_t* col, int64_t num_rows,
+                           int32_t width, const float* add1, const float* add2, float* out, void* stream);
 
 /* ---- K1+K2+K3: periodic k-NN graph + edge features -----------------------------
  * For each query particle q (all n, or query_ids[0..nq) when non-NULL) the k

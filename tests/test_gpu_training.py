@@ -155,6 +155,15 @@ def test_csr_build_and_transposed_aggregation(n, e, width):
     aty = ops.aggregate_csr(y.to(DEV), csr).cpu()
     lhs, rhs = float((ax.double() * y.double()).sum()), float((x.double() * aty.double()).sum())
     assert abs(lhs - rhs) <= 1e-6 * float((ax.double() * y.double()).abs().sum()) + 1e-6      # float32 rounding only
+    # with addends (the residual round's backward, dx + du1 + A^T du2, in one pass): the same bits as the separate adds,
+    # also when the output is one of the addends
+    a1, a2 = torch.randn(n, width, generator=gen).to(DEV), torch.randn(n, width, generator=gen).to(DEV)
+    fused = ops.aggregate_csr(table.to(DEV), csr, add1=a1, add2=a2)
+    assert torch.equal(fused, (a1 + a2) + got.to(DEV))
+    assert torch.equal(ops.aggregate_csr(table.to(DEV), csr, add2=a2), a2 + got.to(DEV))
+    inplace = a1.clone()
+    assert ops.aggregate_csr(table.to(DEV), csr, out=inplace, add1=inplace, add2=a2) is inplace
+    assert torch.equal(inplace, fused)
 
 
 def test_csr_build_rejects_out_of_range_keys():
