@@ -668,7 +668,7 @@ def mlp_backward(fwd: PackedMLP, fwd2: Optional[PackedLinear], bwd: PackedMLP, b
     return du1, du2
 
 
-_WGRAD_WORKSPACE = {}       # device -> workspace of cgnn_weight_grad_x3 (68 MB, contents irrelevant between calls)
+_WGRAD_WORKSPACE = {}       # (device, stream) -> workspace of cgnn_weight_grad_x3 (68 MB, contents irrelevant between calls)
 
 
 def weight_grad(g: torch.Tensor, ld_g: int, out_dim: int, a: torch.Tensor, in_dim: int, n: int, dw: torch.Tensor,
@@ -684,7 +684,7 @@ def weight_grad(g: torch.Tensor, ld_g: int, out_dim: int, a: torch.Tensor, in_di
     if _prec(precision) == _lib.F32X3 and out_dim == 128 and in_dim == 128 and ld_g % 4 == 0 and \
             a.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0 and a.data_ptr() % 16 == 0:
         lib = _lib.load()
-        key = (a.device.type, a.device.index)
+        key = (a.device.type, a.device.index, stream_ptr(a.device))     # per stream: calls on one stream are ordered
         ws = _WGRAD_WORKSPACE.get(key)
         if ws is None:
             ws = _WGRAD_WORKSPACE[key] = torch.empty(lib.cgnn_weight_grad_x3_workspace_bytes(), dtype=torch.uint8,
