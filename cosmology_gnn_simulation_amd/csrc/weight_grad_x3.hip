@@ -12,7 +12,8 @@
 //     a lane loads 16 bytes of a row -- columns 4 i .. 4 i + 3 -- so an instruction reads two whole 512-byte rows, and
 //     the four components are the lane's entries of four column-interleaved 32-wide MFMA tiles (tile t = columns
 //     {4 i + t});
-//   * every wave writes its partial product to a workspace and a second kernel adds the 1024 partials in a fixed order:
+//   * the four waves of a workgroup add their partial products through LDS (wave 1, 2, 3 onto wave 0, in that order),
+//     every workgroup writes one partial to a workspace and a second kernel adds the 256 partials in a fixed order:
 //     the result does not depend on scheduling (same bits every run).
 #include <string.h>
 
@@ -20,9 +21,10 @@
 
 namespace cgnn {
 
-#define CGNN_WGX3_PARTS 1024                      // waves = partial products (256 workgroups of four)
+#define CGNN_WGX3_WAVES 1024                      // waves = row ranges (256 workgroups of four)
+#define CGNN_WGX3_PARTS 256                       // partial products in the workspace: one per workgroup
 #define CGNN_WGX3_PART_FLOATS (16 * 16 * 64 + 128)   // 16 tiles x 16 registers x 64 lanes, then the 128 column sums of g
-#define CGNN_WGX3_GROUPS 4                        // second stage: partials [256 q, 256 q + 256) per thread of group q
+#define CGNN_WGX3_GROUPS 4                        // second stage: partials [64 q, 64 q + 64) per thread of group q
 
 typedef float f32x4w __attribute__((ext_vector_type(4)));
 
@@ -125,7 +127,35 @@ __global__ __launch_bounds__(256) void weight_grad_x3_kernel(const float* __rest
             step(gv, A, B);
         }
     }
-    float* out = part + W * CGNN_WGX3_PART_FLOATS;
+    // the workgroup's four partial products meet in LDS: wave w = 1, 2, 3 in turn lays its accumulators down, wave 0 adds
+    float* const red = reinterpret_cast<float*>(cgnn_smem);        // 16 x 16 x 64 floats + 4 x 64 column sums
+#pragma unroll 1
+    for (int w = 1; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int tg = 0; tg < 4; ++tg)
+#pragma unroll
+                for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) red[((tg * 4 + ta) * 16 + x) * 64 + lane] = acc[tg][ta][x];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) red[16 * 16 * 64 + c * 64 + lane] = cs[c];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int tg = 0; tg < 4; ++tg)
+#pragma unroll
+                for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) acc[tg][ta][x] += red[((tg * 4 + ta) * 16 + x) * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cs[c] += red[16 * 16 * 64 + c * 64 + lane];
+        }
+    }
+    if (wave != 0) return;
+    float* out = part + (int64_t)blockIdx.x * CGNN_WGX3_PART_FLOATS;
 #pragma unroll
     for (int tg = 0; tg < 4; ++tg)
 #pragma unroll
@@ -198,11 +228,16 @@ int cgnn_weight_grad_x3(const float* g, int32_t ld_g, const float* a, int32_t ld
     }
     if (n == 0) return CGNN_OK;
     hipStream_t st = (hipStream_t)stream;
-    int64_t rows_per_wave = (n + CGNN_WGX3_PARTS - 1) / CGNN_WGX3_PARTS;
+    int64_t rows_per_wave = (n + CGNN_WGX3_WAVES - 1) / CGNN_WGX3_WAVES;
     rows_per_wave = (rows_per_wave + 15) / 16 * 16;
     float* part = reinterpret_cast<float*>(workspace);
-    weight_grad_x3_kernel<<<CGNN_WGX3_PARTS / 4, 256, 0, st>>>(g, ld_g, a, ld_a, n, rows_per_wave, part);
-    int rc = check_hip(hipGetLastError(), "cgnn_weight_grad_x3 launch");
+    constexpr int lds = (16 * 16 * 64 + 4 * 64) * (int)sizeof(float);       // 65 KiB
+    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(weight_grad_x3_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds),
+                       "hipFuncSetAttribute(weight_grad_x3)");
+    if (rc != CGNN_OK) return rc;
+    weight_grad_x3_kernel<<<CGNN_WGX3_WAVES / 4, 256, lds, st>>>(g, ld_g, a, ld_a, n, rows_per_wave, part);
+    rc = check_hip(hipGetLastError(), "cgnn_weight_grad_x3 launch");
     if (rc != CGNN_OK) return rc;
     weight_grad_x3_reduce_kernel<<<(CGNN_WGX3_PART_FLOATS + 63) / 64, 256, 0, st>>>(part, dw, ld_dw, col0, db);
     return check_hip(hipGetLastError(), "cgnn_weight_grad_x3 reduce launch");
