@@ -330,6 +330,29 @@ def test_model_edge_message_mode(golden):
     assert rel_err(out["temp_rate"].cpu(), torch.from_numpy(g["edge_mode_temp_rate_cpuref"])) <= 2e-5
 
 
+@pytest.mark.parametrize("d,k,edge_prec,node_prec,tol", [(128, 16, "fp16x2", "fp16x2", 2e-5), (128, 8, "fp32", "fp16x2", 2e-5),
+                                                       (256, 16, "fp16x2", "fp16x2", 2e-5), (64, 8, "fp16x2", "fp32x3", 2e-5),
+                                                       (128, 16, "bf16", "fp16x2", 3e-2)])
+def test_model_edge_message_mode_other_precisions(d, k, edge_prec, node_prec, tol):
+    """message_source='edge' (the engine's extension: the edge updates are what the nodes aggregate, so every kernel of
+    the edge path reaches the outputs) at the f32-accurate precisions and at bf16, against the oracle in that mode."""
+    n, nh, L = 400, 2, 3
+    snap = synthetic.make_snapshot(n, seed=7 + d + k)
+    meta = synthetic.make_metadata()
+    g = data_utils.preprocess(snap["Coordinates"][:W], snap["InternalEnergy"][:W], meta, None, None, 0.0, k, 0.01, 1.0)
+    sd = synthetic.make_state_dict(d, d, nh, L, 3)
+    m = graph_network.EncodeProcessDecode(d, d, nh, L, 3)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    m.edge_precision, m.node_precision, m.message_source = edge_prec, node_prec, "edge"
+    with torch.no_grad():
+        out = m(g)
+        ref = cpu_ref.encode_process_decode(sd, g.x.cpu(), g.edge_index.cpu(), g.edge_attr.cpu(), nh, L,
+                                            message_source="edge")
+    assert rel_err(out["acceleration"].cpu(), ref["acceleration"]) <= tol
+    assert rel_err(out["temp_rate"].cpu(), ref["temp_rate"]) <= tol
+
+
 def test_model_general_edge_order(golden_tiny):
     """Any edge_index is accepted: shuffling the edges takes the atomic aggregation path; same result."""
     g = golden_tiny
