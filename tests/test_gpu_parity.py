@@ -700,6 +700,31 @@ def test_hip_graph_replay_equals_eager(golden_tiny):
     assert torch.equal(out2["acceleration"], eager2["acceleration"])
 
 
+@pytest.mark.parametrize("edge_prec,node_prec", [("bf16", "fp16x2"), ("fp16x2", "fp16x2")])
+def test_hip_graph_replay_at_a_size_that_takes_the_lds_resident_and_planned_paths(edge_prec, node_prec):
+    """Above 4096 / 8192 rows the forward uses kernels that set launch attributes (dynamic LDS for resident weights, ring
+    kernels) and the per-graph aggregation plan: capture and replay must still equal the eager forward bit for bit."""
+    from cosmology_gnn_simulation_amd.graphed import GraphedForward
+    n, k, d, nh, L = 9000, 16, 128, 2, 3
+    snap = synthetic.make_snapshot(n, seed=3)
+    meta = synthetic.make_metadata()
+    g = data_utils.preprocess(snap["Coordinates"][:W], snap["InternalEnergy"][:W], meta, None, None, 0.0, k, 0.01, 1.0)
+    m = graph_network.EncodeProcessDecode(d, d, nh, L, 3)
+    m.load_state_dict(synthetic.make_state_dict(d, d, nh, L, 3))
+    m = m.to(DEV).eval()
+    m.edge_precision, m.node_precision = edge_prec, node_prec
+    with torch.no_grad():
+        eager = m(g)
+    gf = GraphedForward(m, g)
+    out = gf()
+    assert torch.equal(out["acceleration"], eager["acceleration"]) and torch.equal(out["temp_rate"], eager["temp_rate"])
+    x2 = g.x * 0.5
+    with torch.no_grad():
+        eager2 = m(Data(x=x2, edge_index=g.edge_index, edge_attr=g.edge_attr))
+    out2 = gf(x2)
+    assert torch.equal(out2["acceleration"], eager2["acceleration"]) and torch.equal(out2["temp_rate"], eager2["temp_rate"])
+
+
 def test_fixed_k_hint_is_bound_to_its_edge_index(golden_tiny):
     """A caller that reorders the edges of a preprocessed graph (same size, no longer receiver-sorted) must get the
     general path, not the fixed-k kernels on a stale hint: results equal the oracle on the reordered list."""
