@@ -725,6 +725,28 @@ def test_hip_graph_replay_at_a_size_that_takes_the_lds_resident_and_planned_path
     assert torch.equal(out2["acceleration"], eager2["acceleration"]) and torch.equal(out2["temp_rate"], eager2["temp_rate"])
 
 
+def test_large_ragged_batch_equals_its_members():
+    """train.py:247 / validation.py:56 batch several graphs: a three-graph batch big enough for the planned aggregation,
+    the ring kernels and the LDS-resident weights gives every member exactly what it gets alone (rows are independent
+    and every receiver sums its neighbours in the same order)."""
+    k, d, nh, L = 16, 128, 2, 2
+    meta = synthetic.make_metadata()
+    graphs = []
+    for i, n in enumerate((3000, 5000, 2500)):
+        snap = synthetic.make_snapshot(n, seed=20 + i)
+        graphs.append(data_utils.preprocess(snap["Coordinates"][:W], snap["InternalEnergy"][:W], meta, None, None, 0.0, k,
+                                            0.01, 1.0))
+    m = graph_network.EncodeProcessDecode(d, d, nh, L, 3)
+    m.load_state_dict(synthetic.make_state_dict(d, d, nh, L, 3))
+    m = m.to(DEV).eval()
+    m.edge_precision, m.node_precision = "bf16", "fp16x2"
+    with torch.no_grad():
+        alone = [m(g) for g in graphs]
+        out = m(Batch.from_data_list(graphs))
+    for key in ("acceleration", "temp_rate"):
+        assert torch.equal(out[key], torch.cat([a[key] for a in alone])), key
+
+
 def test_fixed_k_hint_is_bound_to_its_edge_index(golden_tiny):
     """A caller that reorders the edges of a preprocessed graph (same size, no longer receiver-sorted) must get the
     general path, not the fixed-k kernels on a stale hint: results equal the oracle on the reordered list."""
