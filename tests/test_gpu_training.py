@@ -117,6 +117,29 @@ def test_weight_grad_three_bf16_terms_is_f32_accurate_and_reproducible(n, col0, 
     assert _close(dw2, g.double().t() @ a64.double(), 1e-5)
 
 
+def test_weight_grad_x3_abi_rejects_what_it_cannot_take():
+    """The C entry itself (the Python wrapper routes such calls to cgnn_weight_grad before they get here): a leading
+    dimension that is not a multiple of 4 -> CGNN_ERR_UNSUPPORTED naming the fallback; a short workspace / NULL pointers
+    -> CGNN_ERR_INVALID_ARG; nothing is launched."""
+    lib = _lib.load()
+    n = 64
+    g = torch.randn(n, 130, device=DEV)
+    a = torch.randn(n, 128, device=DEV)
+    dw = torch.zeros(128, 128, device=DEV)
+    ws = torch.empty(lib.cgnn_weight_grad_x3_workspace_bytes(), dtype=torch.uint8, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.cgnn_weight_grad_x3(g.data_ptr(), 130, a.data_ptr(), 128, n, dw.data_ptr(), 128, 0, None, ws.data_ptr(), ws.numel(), st)
+    assert rc == -2 and b"cgnn_weight_grad" in lib.cgnn_last_error()             # CGNN_ERR_UNSUPPORTED
+    rc = lib.cgnn_weight_grad_x3(a.data_ptr(), 128, a.data_ptr(), 128, n, dw.data_ptr(), 128, 0, None, ws.data_ptr(), 1024, st)
+    assert rc == -1 and b"workspace" in lib.cgnn_last_error()                    # CGNN_ERR_INVALID_ARG
+    rc = lib.cgnn_weight_grad_x3(None, 128, a.data_ptr(), 128, n, dw.data_ptr(), 128, 0, None, ws.data_ptr(), ws.numel(), st)
+    assert rc == -1
+    torch.cuda.synchronize()
+    assert float(dw.abs().sum()) == 0.0
+    rc = lib.cgnn_col_dot2(a.data_ptr(), 128, None, 128, n, 128, dw.data_ptr(), dw.data_ptr(), st)
+    assert rc == -1 and b"cgnn_col_dot2" in lib.cgnn_last_error()
+
+
 def test_mlp_backward_rejects_unsupported_shapes():
     from cosmology_gnn_simulation_amd.training import _TrainMLP
     gen = torch.Generator().manual_seed(0)
