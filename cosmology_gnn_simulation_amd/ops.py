@@ -668,7 +668,7 @@ def mlp_backward(fwd: PackedMLP, fwd2: Optional[PackedLinear], bwd: PackedMLP, b
     return du1, du2
 
 
-_WGRAD_WORKSPACE = {}       # (device, stream) -> workspace of cgnn_weight_grad_x3 (68 MB, contents irrelevant between calls)
+_WGRAD_WORKSPACE = {}       # (device, stream) -> workspace of cgnn_weight_grad_x3 (17 MB, contents irrelevant between calls)
 
 
 def weight_grad(g: torch.Tensor, ld_g: int, out_dim: int, a: torch.Tensor, in_dim: int, n: int, dw: torch.Tensor,
