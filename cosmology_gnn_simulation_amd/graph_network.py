@@ -308,7 +308,7 @@ def _run_round(p: _PackedProcessor, x: torch.Tensor, e: torch.Tensor, src, dst, 
 
 
 def _run_rounds_fused(rounds, x: torch.Tensor, e, src, dst, fixed_k: int, agg: Optional[torch.Tensor],
-                      encoder=None, edge_attr: Optional[torch.Tensor] = None, image=None):
+                      encoder=None, edge_attr: Optional[torch.Tensor] = None, image=None, keep: Optional[dict] = None):
     """All residual rounds under the reference's data flow (aggregation of sender NODE latents): the node
     stream does not read the edge stream, so it runs first and leaves every round's Ps / Pd tables behind (the node
     kernel's epilogue writes round i+1's); then one launch applies all edge updates while each edge tile stays in
@@ -328,6 +328,9 @@ def _run_rounds_fused(rounds, x: torch.Tensor, e, src, dst, fixed_k: int, agg: O
             fused_ok = p.node.precision in _lib.N16_NODE and q.ws_fused.precision == _lib.BF16_N16
             nxt = (q.ws_fused if fused_ok else q.ws, q.wd_fused if fused_ok else q.wd, ps_all[i + 1], pd_all[i + 1], fmt)
         x = ops.node_block(p.node, p.wx, p.wa, x, agg, x, True, nxt)
+    if keep is not None:      # tests: what the one-launch edge stream is about to consume (EncodeProcessDecode.keep_stream_inputs)
+        keep.update(ps_all=ps_all, pd_all=pd_all, src=src, dst=dst, edge_attr=edge_attr, p_format=fmt,
+                    e_in=None if e is None else e.to_rows())
     # `encoder` (the packed edge encoder) given: the initial edge latents are computed inside the same launch and
     # never written to memory (e is None then)
     if image is not None:      # cgnn_edge_stream_run: the rounds (and the encoder, if it is part of the image) as one image
@@ -420,6 +423,9 @@ class EncodeProcessDecode(nn.Module):
         # which one-launch kernel: "tile32" = cgnn_edge_stream_run (32-edge MFMA tiles, one wave per SIMD, default),
         # "tile16" = cgnn_edge_stream (16-edge tiles, two waves per SIMD; the first generation, kept for comparison)
         self.edge_stream_kernel = "tile32"
+        # tests only: forward_with_latents() also returns the one-launch edge stream's inputs (every round's Ps / Pd table,
+        # the renumbered edge list and edge features) under "stream_inputs", so that sampled edge rows can be recomputed
+        self.keep_stream_inputs = False
         self._packed = None
         self._train_packed = None
 
@@ -598,9 +604,10 @@ class EncodeProcessDecode(nn.Module):
                 scratch = (ps, pd, agg, e_upd)
             projected = False
             rounds = P["rounds"]
+            keep = {} if (want_latents and getattr(self, "keep_stream_inputs", False)) else None
             if fuse:
                 xl, el = _run_rounds_fused(rounds, xl, el, src, dst, fixed_k, agg,
-                                           P["enc_edge"] if enc_in_stream else None, edge_attr, image)
+                                           P["enc_edge"] if enc_in_stream else None, edge_attr, image, keep)
                 rounds = []
             for i, p in enumerate(rounds):
                 # residual streams updated in place (reference graph_network.py:181-182); the node kernel also
@@ -612,6 +619,9 @@ class EncodeProcessDecode(nn.Module):
             out = {"acceleration": ops.mlp_rows(P["dec_acc"], xl), "temp_rate": ops.mlp_rows(P["dec_tr"], xl)}
             if want_latents:
                 out["x_latent"], out["edge_latent"] = xl, el.to_rows()
+                if keep:       # engine numbering (the locality order), next to the edge latents in that same numbering
+                    keep["edge_latent_sorted"] = out["edge_latent"]
+                    out["stream_inputs"] = keep
             if plan is not None:   # back to the caller's particle numbering
                 out["acceleration"] = ops.gather_rows(out["acceleration"], inv)
                 out["temp_rate"] = ops.gather_rows(out["temp_rate"], inv)

@@ -3,6 +3,7 @@ compared bit-for-bit on owned nodes against the unsharded forward."""
 import pytest
 import torch
 
+import edge_checks as ec
 from cosmology_gnn_simulation_amd import data_utils, dist as cdist, graph_network, ops, synthetic
 
 pytestmark = pytest.mark.gpu
@@ -90,6 +91,12 @@ def _sharded_vs_unsharded(n, k, d, L, world, msg, prec, seed, full_size=False):
             if r == 0:
                 got_e = rn.el.to_rows()
                 assert float((got_e - want["edge_latent"]).norm() / want["edge_latent"].norm()) <= 2e-2
+                # per row (a norm over the whole tile's edges cannot see one wrong 32-edge tile); ghost senders'
+                # projections are rounded to bf16 from a different f32 summation order, hence a rounding-level gate
+                ec.assert_rows_close(got_e, want["edge_latent"], 5e-2, f"{'cfg' if full_size else ''} rank-0 edge latents")
+                for tile in (0, got_e.shape[0] // 64, (got_e.shape[0] + 31) // 32 - 1):
+                    with ec.corrupted_tile(got_e, tile):
+                        ec.must_fail(ec.assert_rows_close, got_e, want["edge_latent"], 5e-2)
             continue
         # the owned receivers' edge latents: ghost senders' projections come from the stand-alone projection kernel
         # (different f32 summation order before the bf16 rounding than the node kernel's epilogue), so these agree to
@@ -98,3 +105,4 @@ def _sharded_vs_unsharded(n, k, d, L, world, msg, prec, seed, full_size=False):
         want_e = want["edge_latent"].view(n, k, -1)[sh.owned_global].reshape(-1, got_e.shape[1])
         tol = 2e-2 if prec == "bf16" else 1e-5
         assert float((got_e - want_e).norm() / want_e.norm()) <= tol
+        ec.assert_rows_close(got_e, want_e, 5e-2 if prec == "bf16" else 1e-4, f"rank {r} edge latents")
