@@ -25,56 +25,9 @@
 
 #include <type_traits>
 
-#include "n16.hpp"
+#include "s32.hpp"
 
 namespace cgnn {
-
-#define CGNN_S32_WAVES 4
-#define CGNN_S32_BLOCK (CGNN_S32_WAVES * 64)
-#define CGNN_S32_SLOTS 4
-#ifndef CGNN_S32_PD
-#define CGNN_S32_PD 2      // groups of LDS weight fragments in flight ahead of the MFMAs
-#endif
-
-template <int DT>
-struct S32Geom {
-    static constexpr int D = 32 * DT, KS = 2 * DT, NROW = DT;
-    static constexpr unsigned W_BYTES = (unsigned)D * D * 2;          // one D x D bf16 layer, 1-KiB fragments (o, ks)
-    static constexpr unsigned VEC_OFF = W_BYTES;                       // bias[D], gamma[D], beta[D] (f32)
-    static constexpr unsigned RAW = W_BYTES + 3u * D * 4;
-    static constexpr unsigned PIECE = CGNN_S32_WAVES * 1024u;          // one 1-KiB LDS-DMA instruction per wave
-    static constexpr unsigned STRIDE = (RAW + PIECE - 1) / PIECE * PIECE;
-    static constexpr int NP = (int)(STRIDE / PIECE);                   // pieces per wave and chunk
-    static constexpr unsigned LDS = CGNN_S32_SLOTS * STRIDE;
-};
-
-static size_t s32_stride(int latent) {
-    switch (latent) {
-        case 32: return S32Geom<1>::STRIDE;
-        case 64: return S32Geom<2>::STRIDE;
-        case 128: return S32Geom<4>::STRIDE;
-        default: return 0;
-    }
-}
-
-struct S32Args {
-    const char* image;       // chunk c at image + c * STRIDE, consumption order: [encoder layers] round 0 layers, round 1 ...
-    int32_t rounds, nh;      // a round is nh + 1 chunks
-    int32_t enc_in_dim;      // > 0: the first nh + 1 chunks are the edge encoder, fed from edge_attr
-};
-
-// ---- vector-memory waits -------------------------------------------------------------------------------------------
-// A wave's vector-memory operations retire in issue order, so "X has landed" is a counted s_waitcnt: at most as many
-// operations outstanding as the wave has issued since X.  The loop's operations come in a fixed order (see the
-// schedule at the kernel), so the counts are constants; a smaller count than the true one only waits longer.
-#define CGNN_S32_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-template <int N>
-__device__ __forceinline__ void vm_wait_const() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-typedef __attribute__((address_space(3))) void* LdsVoidPtrG;
-typedef const __attribute__((address_space(1))) void* GlobalVoidPtrG;
 
 // ---- the ring -------------------------------------------------------------------------------------------------------
 // Four slots.  Step s computes out of slot s % 4.  Between the two tiles' blocks of step s every wave waits for its
@@ -216,39 +169,6 @@ __device__ __forceinline__ void lds_wait2i(u32x4& a, u32x4& b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+a"(a), "+a"(b) : "n"(IMM));
 }
 
-// A block's MFMAs are numbered 0 .. M-1 ("slots"); `fill(slot)` runs right behind MFMA `slot` and a scheduling barrier
-// pins it there: the place for the OTHER tile's vector work and this wave's memory instructions, whose issue then
-// overlaps the matrix pipe (left alone, hipcc gathers the independent vector work in front of the block).
-struct NoFill32 {
-    template <int Q>
-    __device__ __forceinline__ void run() const {}
-};
-template <class F>
-struct FnFill32 {
-    F f;
-    template <int Q>
-    __device__ __forceinline__ void run() const {
-        f(std::integral_constant<int, Q>{});
-    }
-};
-template <class F>
-__device__ __forceinline__ FnFill32<F> make_fill(F f) {
-    return FnFill32<F>{f};
-}
-
-template <int NROW, int KS>
-struct WBlock {
-    static constexpr int M = NROW * KS, GS = M < 4 ? M : 4, NG = M / GS, PD = CGNN_S32_PD;
-    // weight-fragment reads issued between MFMA `q` and its fill (fragment q + PD * GS, if the layer has one)
-    static constexpr int fragtop(int q) { return (q + PD * GS < M) ? 1 : 0; }
-    // ... in front of MFMAs (q0, q1]
-    static constexpr int frags_between(int q0, int q1) {
-        int n = 0;
-        for (int x = q0 + 1; x <= q1; ++x) n += fragtop(x);
-        return n;
-    }
-};
-
 // acc[o] += W[32 o .. 32 o + 31, :] . in ; fragment m = o * KS + ks (1 KiB, lane-linear) at addr + m * 1024.  The LDS
 // reads and their counted waits are written by hand (hipcc waits lgkmcnt(0) before every group otherwise); PD groups
 // of four fragments are in flight ahead of the MFMAs.  Rows are finished one after the other (o outermost).
@@ -355,46 +275,6 @@ __device__ __forceinline__ void wblock32p(f32x16 (&acc)[NROW], const bf16x8 (&in
     }, std::make_integer_sequence<int, NG>{});
 }
 
-// P rows (CGNN_P_BF16_S32: lane (r, h) owns the 16-byte pieces 2 t + s of its half of the row = the B operand of k-step
-// (t, s)) enter the accumulators through the matrix pipe: A = a constant 0/1 selector that copies k = 8 h' + j of
-// k-step s to row 16 s + 8 (j >> 2) + 4 h' + (j & 3).  acc[t] = Ps[src] + Pd[dst] (exact products, f32 sums).
-// 4 DT MFMAs = slots 0 .. 4 DT - 1.
-__device__ __forceinline__ bf16x8 p32_selector(int lane, int s) {
-    const int m = lane & 31, hh = lane >> 5;
-    bf16x8 a;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = (__bf16)((m == 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3)) ? 1.0f : 0.0f);
-    return a;
-}
-template <int DT, class Fill>
-__device__ __forceinline__ void selp32(f32x16 (&acc)[DT], const bf16x8 (&ps)[2 * DT], const bf16x8 (&pd)[2 * DT], bf16x8 sel0,
-                                       bf16x8 sel1, const Fill& fill) {
-#ifdef CGNN_S32_ABLATE_SELP
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    return;
-#endif
-    static_for_each([&](auto tc) __attribute__((always_inline)) {
-        constexpr int t = decltype(tc)::value;
-        f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel0, ps[2 * t], c, 0, 0, 0);
-        fill.template run<4 * t>();
-        __builtin_amdgcn_sched_barrier(0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel1, ps[2 * t + 1], c, 0, 0, 0);
-        fill.template run<4 * t + 1>();
-        __builtin_amdgcn_sched_barrier(0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel0, pd[2 * t], c, 0, 0, 0);
-        fill.template run<4 * t + 2>();
-        __builtin_amdgcn_sched_barrier(0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel1, pd[2 * t + 1], c, 0, 0, 0);
-        acc[t] = c;
-        fill.template run<4 * t + 3>();
-        __builtin_amdgcn_sched_barrier(0);
-    }, std::make_integer_sequence<int, DT>{});
-}
-
 // P-row loads from inline asm (the compiler would guard registers loaded across the ring's LDS-DMA with vmcnt(0)),
 // straight into accumulation registers; 32-bit lane offset + uniform 64-bit table base.  The caller waits (counted)
 // and then calls p32_ready().
@@ -448,12 +328,6 @@ __device__ __forceinline__ void pack32_run(Tile32<DT>& X) {
         constexpr int u = decltype(uc)::value + S0;
         if constexpr (u < S1) pack32_slice<RELU, DT, u>(X);
     }, std::make_integer_sequence<int, (S1 > S0 ? S1 - S0 : 0)>{});
-}
-
-__device__ __forceinline__ float half_swap_sum(float s) {     // s[lane] + s[lane ^ 32] on the vector pipe
-    float a = s, b = s;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    return a + b;
 }
 
 // LayerNorm (eps 1e-5, biased variance, affine) of X.acc over the 32 DT features of each edge, then
@@ -610,16 +484,6 @@ __device__ __forceinline__ void bias_rows32(f32x16 (&acc)[DT], unsigned vec_addr
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[t][4 * g + c] = v[c];
         }
-}
-
-// share [q * n / nq, (q + 1) * n / nq) of n slices for slot q of nq
-constexpr int share_lo(int n, int nq, int q) { return (int)((long)q * n / nq); }
-constexpr int share_hi(int n, int nq, int q) { return (int)((long)(q + 1) * n / nq); }
-// the last slot before q that ran a slice of an n-slice job (-1: none)
-constexpr int prev_share_slot(int n, int nq, int q) {
-    for (int x = q - 1; x >= 0; --x)
-        if (share_hi(n, nq, x) > share_lo(n, nq, x)) return x;
-    return -1;
 }
 
 #ifdef CGNN_S32_STAMPS   // developer build: s_memtime stamps of one workgroup's waves over one pass (printed by the launcher)

@@ -308,7 +308,8 @@ def _run_round(p: _PackedProcessor, x: torch.Tensor, e: torch.Tensor, src, dst, 
 
 
 def _run_rounds_fused(rounds, x: torch.Tensor, e, src, dst, fixed_k: int, agg: Optional[torch.Tensor],
-                      encoder=None, edge_attr: Optional[torch.Tensor] = None, image=None, keep: Optional[dict] = None):
+                      encoder=None, edge_attr: Optional[torch.Tensor] = None, image=None, keep: Optional[dict] = None,
+                      stream_kernel: str = "tile32", stream_lag: int = 1):
     """All residual rounds under the reference's data flow (aggregation of sender NODE latents): the node
     stream does not read the edge stream, so it runs first and leaves every round's Ps / Pd tables behind (the node
     kernel's epilogue writes round i+1's); then one launch applies all edge updates while each edge tile stays in
@@ -334,7 +335,8 @@ def _run_rounds_fused(rounds, x: torch.Tensor, e, src, dst, fixed_k: int, agg: O
     # `encoder` (the packed edge encoder) given: the initial edge latents are computed inside the same launch and
     # never written to memory (e is None then)
     if image is not None:      # cgnn_edge_stream_run: the rounds (and the encoder, if it is part of the image) as one image
-        e = ops.edge_stream_run(image, ps_all, pd_all, src, dst, e, e, edge_attr if image.enc_in else None)
+        e = ops.edge_stream_run(image, ps_all, pd_all, src, dst, e, e, edge_attr if image.enc_in else None,
+                                kernel=stream_kernel, lag=stream_lag, fixed_k=fixed_k)
     else:
         e = ops.edge_stream([p.edge for p in rounds], ps_all, pd_all, src, dst, e, e, encoder, edge_attr)
     return x, e
@@ -420,9 +422,11 @@ class EncodeProcessDecode(nn.Module):
         self.train_precision = "fp32"  # arithmetic of the differentiable forward + backward: "fp32" or "fp32x3"
         self.locality_sort = True     # run in the k-NN build's spatial order when the graph carries it
         self.fuse_rounds = True       # x_j mode: all rounds of the edge stream in one launch
-        # which one-launch kernel: "tile32" = cgnn_edge_stream_run (32-edge MFMA tiles, one wave per SIMD, default),
-        # "tile16" = cgnn_edge_stream (16-edge tiles, two waves per SIMD; the first generation, kept for comparison)
+        # which one-launch kernel: "tile32" = cgnn_edge_stream_run (32-edge MFMA tiles, one wave per SIMD, two tiles per
+        # wave), "tile32w" = cgnn_edge_stream_run_w8 (32-edge tiles, two waves per SIMD, one tile each; latent 128 only,
+        # other shapes take "tile32"), "tile16" = cgnn_edge_stream (16-edge tiles; the first generation, kept for comparison)
         self.edge_stream_kernel = "tile32"
+        self.edge_stream_lag = 1      # "tile32w": second wave of a SIMD one layer behind the first (0: in step)
         # tests only: forward_with_latents() also returns the one-launch edge stream's inputs (every round's Ps / Pd table,
         # the renumbered edge list and edge features) under "stream_inputs", so that sampled edge rows can be recomputed
         self.keep_stream_inputs = False
@@ -451,7 +455,7 @@ class EncodeProcessDecode(nn.Module):
             return self._packed[1]
         D, H, nh, L = self._latent_size, self._mlp_hidden_size, self._mlp_num_hidden_layers, len(self.processor)
         # cgnn_edge_stream_run (all rounds of the edge stream in one launch, 32-edge tiles) under the reference's data flow
-        tile32 = (self.fuse_rounds and self.message_source == "x_j" and self.edge_stream_kernel == "tile32" and L > 0 and
+        tile32 = (self.fuse_rounds and self.message_source == "x_j" and self.edge_stream_kernel in ("tile32", "tile32w") and L > 0 and
                   ops._prec(self.edge_precision) == _lib.BF16 and ops.StreamImage.supported(D, H, nh, L))
         enc_edge = _pack_mlp(self.encoder.edge_model, self.edge_precision)
         enc_in_image = tile32 and ops.StreamImage.supported(D, H, nh, L, enc_edge.in_dim)
@@ -606,8 +610,11 @@ class EncodeProcessDecode(nn.Module):
             rounds = P["rounds"]
             keep = {} if (want_latents and getattr(self, "keep_stream_inputs", False)) else None
             if fuse:
+                w8 = (image is not None and self.edge_stream_kernel == "tile32w" and
+                      ops.stream_w8_supported(image.latent, image.nh))
                 xl, el = _run_rounds_fused(rounds, xl, el, src, dst, fixed_k, agg,
-                                           P["enc_edge"] if enc_in_stream else None, edge_attr, image, keep)
+                                           P["enc_edge"] if enc_in_stream else None, edge_attr, image, keep,
+                                           "tile32w" if w8 else "tile32", int(getattr(self, "edge_stream_lag", 1)))
                 rounds = []
             for i, p in enumerate(rounds):
                 # residual streams updated in place (reference graph_network.py:181-182); the node kernel also

@@ -371,12 +371,22 @@ class StreamImage:
         self._keep = (list(mlps), encoder)     # the copies are asynchronous: keep the sources alive
 
 
+def stream_w8_supported(latent: int, nh: int) -> bool:
+    """Whether ``cgnn_edge_stream_run_w8`` (two waves per SIMD) is built for this shape."""
+    return bool(_lib.load().cgnn_edge_stream_w8_supported(latent, nh))
+
+
 def edge_stream_run(image: StreamImage, ps_all: torch.Tensor, pd_all: torch.Tensor, src: torch.Tensor, dst: torch.Tensor,
                     e_in: Optional[TiledRows], e_out: Optional[TiledRows] = None,
-                    edge_attr: Optional[torch.Tensor] = None) -> TiledRows:
-    """All residual edge updates of ``image`` in one launch (``cgnn_edge_stream_run``).  ``ps_all`` / ``pd_all``:
-    ``[rounds, N, latent]`` bf16 tables in ``CGNN_P_BF16_S32`` format.  When the image starts with the encoder the
-    initial latents come from ``edge_attr`` and ``e_in`` is ignored."""
+                    edge_attr: Optional[torch.Tensor] = None, kernel: str = "tile32", lag: int = 1,
+                    fixed_k: int = 0) -> TiledRows:
+    """All residual edge updates of ``image`` in one launch.  ``ps_all`` / ``pd_all``: ``[rounds, N, latent]`` bf16
+    tables in ``CGNN_P_BF16_S32`` format.  When the image starts with the encoder the initial latents come from
+    ``edge_attr`` and ``e_in`` is ignored.  ``kernel``: ``"tile32"`` = ``cgnn_edge_stream_run`` (one wave per SIMD, two
+    tiles per wave), ``"tile32w"`` = ``cgnn_edge_stream_run_w8`` (two waves per SIMD, one tile each; ``lag`` and
+    ``fixed_k`` as in include/cgnn.h: pass the graph's fixed in-degree only when ``dst[e] == e // fixed_k``)."""
+    if kernel not in ("tile32", "tile32w"):
+        raise CgnnError(f"edge_stream_run: unknown kernel {kernel!r}")
     src, dst = i32c(src, "src"), i32c(dst, "dst")
     ne, latent = src.numel(), image.latent
     if image.enc_in:
@@ -397,13 +407,16 @@ def edge_stream_run(image: StreamImage, ps_all: torch.Tensor, pd_all: torch.Tens
             raise CgnnError(f"edge_stream_run: {name} must be a contiguous bfloat16 [rounds, N, latent] table")
     if dst.numel() != ne or e_out.n != ne or e_out.width != latent:
         raise CgnnError("edge_stream_run: src/dst/e_out do not match the edge latents")
+    args = (image.buf.data_ptr(), image.buf.numel(), latent, image.nh, image.rounds, image.enc_in, ps_all.data_ptr(),
+            pd_all.data_ptr(), ps_all.stride(0), src.data_ptr(), dst.data_ptr(), ne,
+            e_in.buf.data_ptr() if e_in is not None else None, e_out.buf.data_ptr(), ptr(edge_attr),
+            edge_attr.stride(0) if edge_attr is not None else 0)
     with _timed("edge_stream", src.device):
-        check(_lib.load().cgnn_edge_stream_run(image.buf.data_ptr(), image.buf.numel(), latent, image.nh, image.rounds,
-                                               image.enc_in, ps_all.data_ptr(), pd_all.data_ptr(), ps_all.stride(0),
-                                               src.data_ptr(), dst.data_ptr(), ne,
-                                               e_in.buf.data_ptr() if e_in is not None else None, e_out.buf.data_ptr(),
-                                               ptr(edge_attr), edge_attr.stride(0) if edge_attr is not None else 0,
-                                               stream_ptr(src.device)), "cgnn_edge_stream_run")
+        if kernel == "tile32w":
+            check(_lib.load().cgnn_edge_stream_run_w8(*args, int(lag), int(fixed_k), stream_ptr(src.device)),
+                  "cgnn_edge_stream_run_w8")
+        else:
+            check(_lib.load().cgnn_edge_stream_run(*args, stream_ptr(src.device)), "cgnn_edge_stream_run")
     return e_out
 
 

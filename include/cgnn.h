@@ -256,6 +256,22 @@ int cgnn_edge_stream_run(const void* image, size_t image_bytes, int32_t latent, 
                          int64_t round_stride, const int32_t* src, const int32_t* dst, int64_t num_edges,
                          const float* e_in, float* e_out, const float* edge_attr, int32_t ld_attr, void* stream);
 
+/* ---- the same, third generation: 32 edges per MFMA tile, TWO waves per SIMD, one tile per wave ----------------------
+ * Same image, tables, layouts and arithmetic as cgnn_edge_stream_run (reference graph_network.py:57,:89-90,:182); the
+ * two co-resident waves of a SIMD overlap one's vector work (bf16 pack, LayerNorm) with the other's matrix work in
+ * hardware.  lag = 1: the second wave of every SIMD runs one layer behind the first (their LayerNorms never coincide),
+ * lag = 0: in step.  Results do not depend on lag.  fixed_k > 0: the caller guarantees dst[e] == e / fixed_k (receiver-
+ * sorted, fixed in-degree: the layout of data_utils.preprocess, as for cgnn_aggregate); for fixed_k in {8, 16, 32, 64, ...}
+ * a tile's receiver rows are then fetched once and broadcast (same results); 0: any edge list.
+ * Built for hidden == latent == 128 and 1..3 hidden layers
+ * (cgnn_edge_stream_w8_supported); other shapes: cgnn_edge_stream_run. */
+int cgnn_edge_stream_w8_supported(int32_t latent, int32_t num_hidden_layers);
+int cgnn_edge_stream_run_w8(const void* image, size_t image_bytes, int32_t latent, int32_t num_hidden_layers,
+                            int32_t num_rounds, int32_t enc_in_dim, const void* ps_all, const void* pd_all,
+                            int64_t round_stride, const int32_t* src, const int32_t* dst, int64_t num_edges,
+                            const float* e_in, float* e_out, const float* edge_attr, int32_t ld_attr, int32_t lag,
+                            int32_t fixed_k, void* stream);
+
 /* ---- backward of a row-wise MLP (+LayerNorm): the node stream of train.py:263 ------------------------
  * In reference-faithful mode only the node path carries gradient (the edge models' parameters get
  * none), so training needs the backward of cgnn_mlp_rows / cgnn_node_block and the transpose of the

@@ -8,6 +8,7 @@ SRC=$1; shift
 STEM=$(basename "$SRC" .hip)
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$ROOT/include -Wall -Wno-unused-function"
 [ "$STEM" = edge_stream32 ] && [ -z "$NO_S32_FLAGS" ] && FLAGS="$FLAGS -mllvm -amdgpu-mfma-vgpr-form=1"
+[ "$STEM" = edge_stream32w ] && FLAGS="$FLAGS -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize"
 OTHERS=$(ls $CS/build/*.o | grep -v "/$STEM.o")
 for spec in "$@"; do
   name=${spec%%=*}; defs=${spec#*=}

@@ -83,12 +83,20 @@ def _emulate(src, dst, ps, pd, mlps, enc, attr, e0):
     return e
 
 
-def _run(src, dst, ps, pd, mlps, enc, attr, e0):
+KERNELS = [("tile32", 0), ("tile32w", 0), ("tile32w", 1)]      # (kernel, lag): see ops.edge_stream_run
+
+
+def _kernel_applies(kernel, d, nh):
+    return kernel == "tile32" or ops.stream_w8_supported(d, nh)
+
+
+def _run(src, dst, ps, pd, mlps, enc, attr, e0, kernel=("tile32", 0), fixed_k=0):
     packed = [ops.PackedMLP([(lin[0][0], None)] + lin[1:], ln, "bf16") for lin, ln in mlps]
     penc = ops.PackedMLP(enc[0], enc[1], "bf16") if enc is not None else None
     image = ops.StreamImage(packed, penc)
     e_in = None if enc is not None else ops.TiledRows.from_rows(e0)
-    out = ops.edge_stream_run(image, _s32_table(ps), _s32_table(pd), src, dst, e_in, None, attr if enc is not None else None)
+    out = ops.edge_stream_run(image, _s32_table(ps), _s32_table(pd), src, dst, e_in, None, attr if enc is not None else None,
+                              kernel=kernel[0], lag=kernel[1], fixed_k=fixed_k)
     torch.cuda.synchronize()
     return out.to_rows()
 
@@ -111,10 +119,13 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("kernel", KERNELS, ids=lambda kk: f"{kk[0]}-lag{kk[1]}")
 @pytest.mark.parametrize("n,k,d,nh,rounds,with_enc,ragged", CASES)
-def test_edge_stream_run_matches_bf16_emulation(n, k, d, nh, rounds, with_enc, ragged):
+def test_edge_stream_run_matches_bf16_emulation(n, k, d, nh, rounds, with_enc, ragged, kernel):
+    if not _kernel_applies(kernel[0], d, nh):
+        pytest.skip("the two-waves-per-SIMD kernel is built for latent 128")
     prob = _problem(1000 + n + d + rounds, n, k, d, nh, rounds, with_enc, ragged)
-    got = _run(*prob)
+    got = _run(*prob, kernel=kernel)
     want = _emulate(*prob)
     assert got.shape == want.shape
     scale = float(want.abs().max())
@@ -125,17 +136,43 @@ def test_edge_stream_run_matches_bf16_emulation(n, k, d, nh, rounds, with_enc, r
     assert torch.isfinite(got).all()
 
 
-def test_edge_stream_run_is_deterministic_and_in_place():
+@pytest.mark.parametrize("kernel", KERNELS, ids=lambda kk: f"{kk[0]}-lag{kk[1]}")
+def test_edge_stream_run_is_deterministic_and_in_place(kernel):
     prob = _problem(5, 5000, 16, 128, 2, 4, False)
-    a = _run(*prob)
-    b = _run(*prob)
+    a = _run(*prob, kernel=kernel)
+    b = _run(*prob, kernel=kernel)
     assert torch.equal(a, b)
     src, dst, ps, pd, mlps, enc, attr, e0 = prob
     packed = [ops.PackedMLP([(lin[0][0], None)] + lin[1:], ln, "bf16") for lin, ln in mlps]
     image = ops.StreamImage(packed, None)
     e = ops.TiledRows.from_rows(e0)
-    ops.edge_stream_run(image, _s32_table(ps), _s32_table(pd), src, dst, e, e)        # e_out aliases e_in
+    ops.edge_stream_run(image, _s32_table(ps), _s32_table(pd), src, dst, e, e, kernel=kernel[0], lag=kernel[1])   # e_out aliases e_in
     assert torch.equal(e.to_rows(), a)
+
+
+@pytest.mark.parametrize("k", [8, 16, 32, 64])
+@pytest.mark.parametrize("lag", [0, 1])
+def test_receiver_rows_by_broadcast_on_fixed_k_graphs(k, lag):
+    """The layout data_utils.preprocess emits (dst[e] == e // k): cgnn_edge_stream_run_w8 fetches a tile's receiver rows once
+    and broadcasts them through LDS.  Same P values through the same MFMAs: bit-equal to the gathering path, and equal to
+    the emulation."""
+    n = 20000 // k
+    for enc in (True, False):
+        src, dst, ps, pd, mlps, encw, attr, e0 = _problem(70 + k, n, k, 128, 2, 3, enc)
+        dst = torch.arange(n, dtype=torch.int32, device=DEV).repeat_interleave(k)
+        prob = (src, dst, ps, pd, mlps, encw, attr, e0)
+        got = _run(*prob, kernel=("tile32w", lag), fixed_k=k)
+        assert torch.equal(got, _run(*prob, kernel=("tile32w", lag), fixed_k=0))
+        want = _emulate(*prob)
+        assert float((got - want).abs().max()) <= 1e-2 * float(want.abs().max())
+        assert float((got - want).norm() / want.norm()) <= 1e-3
+
+
+def test_two_waves_per_simd_kernel_does_not_depend_on_the_lag():
+    """lag only shifts WHEN the second wave of a SIMD runs a layer: same arithmetic per tile, same bits."""
+    for seed, enc in ((7, True), (8, False)):
+        prob = _problem(seed, 9000, 16, 128, 2, 3, enc, 5)
+        assert torch.equal(_run(*prob, kernel=("tile32w", 0)), _run(*prob, kernel=("tile32w", 1)))
 
 
 def test_edge_stream_run_one_round_at_a_time_equals_all_rounds():
