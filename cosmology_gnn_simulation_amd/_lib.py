@@ -93,7 +93,7 @@ def load() -> C.CDLL:
     lib.cgnn_edge_stream_image_bytes.argtypes = [i32, i32, i32, i32]
     lib.cgnn_edge_stream_image_build.argtypes = [C.POINTER(Mlp), i32, C.POINTER(Mlp), i32, vp, sz, vp]
     lib.cgnn_edge_stream_run.argtypes = [vp, sz, i32, i32, i32, i32, vp, vp, i64, vp, vp, i64, vp, vp, vp, i32, vp]
-    lib.cgnn_edge_stream_w8_supported.argtypes = [i32, i32]
+    lib.cgnn_edge_stream_w8_supported.argtypes = [i32, i32, i32]
     lib.cgnn_edge_stream_run_w8.argtypes = [vp, sz, i32, i32, i32, i32, vp, vp, i64, vp, vp, i64, vp, vp, vp, i32, i32, i32, vp]
     lib.cgnn_aggregate.argtypes = [vp, i32, vp, vp, i64, i32, i64, i32, vp, vp]
     lib.cgnn_aggregate_plan_bytes.restype = sz

@@ -8,15 +8,22 @@
 // f32 latents of both tiles have to be parked in accumulation registers (256 moves per pass).  Here
 //   * 512-thread workgroups: TWO waves per SIMD, ONE 32-edge tile each, the same v_mfma_f32_32x32x16_bf16 economy (a
 //     1-KiB LDS fragment feeds a 32-cycle MFMA, the ring step serves 256 edges per CU).  The hardware interleaves the
-//     two waves: one wave's bf16 pack, LayerNorm and waits run under the other's MFMAs, and the SIMD issues two vector
-//     instructions in the time a lone wave issues one;
+//     two waves: a wave that only issues vector instructions runs beside a wave that only issues MFMAs at full matrix
+//     rate and 5.2 cycles per vector instruction (scripts/dev/probe_mfma_valu.hip);
 //   * 256 registers per wave, all architectural: f32 latent 64, accumulators 64, bf16 operand 32 (+ the next operand,
 //     packed row tile by row tile as accumulators die), weight fragments, P rows.  Nothing is parked; every memory
 //     operation except the fragment reads is visible to the compiler (no hand-counted register loads);
-//   * optional LAG: waves 4-7 (the second wave of every SIMD) run one ring step behind waves 0-3, so that one wave's
-//     LayerNorm (vector pipe only) coincides with its partner's matrix work instead of its partner's LayerNorm.
+//   * LAG 1: waves 4-7 (the second wave of every SIMD) run one ring step behind waves 0-3, so that one wave's
+//     LayerNorm (vector pipe only) meets its partner's matrix work instead of its partner's LayerNorm;
+//   * P rows through LDS.  A lane's half of a sender row is one 128-byte line; gathering it as eight 16-byte pieces costs
+//     eight load instructions that each touch 64 lines (the texture addresser takes a line per cycle: 4 k cycles per
+//     pass and CU, and the issuing waves queue behind it).  Here four lanes fetch 64 contiguous bytes of a line by LDS-DMA
+//     (16 lines per instruction) into a 4-KiB staging area, XOR-swizzled so that the B-operand pieces come back with
+//     conflict-free ds_read_b128; the receiver rows of a tile (fixed in-degree k, receiver-sorted: at most four) are
+//     fetched by ONE load and broadcast through LDS.  The kernel therefore takes fixed-k graphs (8 <= k, k | 32 or 32 | k:
+//     what data_utils.preprocess emits); other edge lists run cgnn_edge_stream_run.
 // Same image as cgnn_edge_stream_run (cgnn_edge_stream_image_build), same P tables (CGNN_P_BF16_S32), same numerics
-// (bf16 operands, f32 accumulation, f32 LayerNorm and residual).
+// (bf16 operands, f32 accumulation, f32 LayerNorm and residual; LayerNorm's variance as E[x^2] - mean^2).
 #include <string.h>
 
 #include <type_traits>
@@ -27,13 +34,16 @@ namespace cgnn {
 
 #define CGNN_W8_WAVES 8
 #define CGNN_W8_BLOCK (CGNN_W8_WAVES * 64)
-#define CGNN_W8_SLOTS 4
+#define CGNN_W8_SLOTS 3
 #define CGNN_IC(x) std::integral_constant<int, (x)> {}
 #ifndef CGNN_W8_GS
 #define CGNN_W8_GS 4       // LDS weight fragments per group
 #endif
 #ifndef CGNN_W8_LN_EARLY
-#define CGNN_W8_LN_EARLY 0    // LayerNorm slices (of 2 * latent / 32) done in the output layer's own step, before the barrier
+#define CGNN_W8_LN_EARLY 0    // LayerNorm affine slices (of 2 * latent / 32) done in the output layer's own step, before the barrier
+#endif
+#ifndef CGNN_W8_LN_ASM
+#define CGNN_W8_LN_ASM 0      // LayerNorm's gamma / beta: 0 = plain LDS loads, 1 = hand-issued per slice, 2 = hand-issued one slice ahead
 #endif
 #ifndef CGNN_W8_PD
 #define CGNN_W8_PD 1       // groups in flight ahead of the MFMAs
@@ -69,14 +79,20 @@ struct W8Geom {
     static constexpr unsigned LNBUF_BYTES = 2u * D * 4u;
     static constexpr unsigned PDST_OFF = LNBUF_OFF + 2u * LNBUF_BYTES;           // per wave: the tile's receiver P rows (<= 4 rows)
     static constexpr unsigned PDST_BYTES = 64u * 16u;
-    static constexpr unsigned LDS = PDST_OFF + CGNN_W8_WAVES * PDST_BYTES;
+    static constexpr unsigned PSST_OFF = PDST_OFF + CGNN_W8_WAVES * PDST_BYTES;  // per wave: half of every sender half-row of the tile
+    static constexpr unsigned PSST_BYTES = 64u * (unsigned)D / 2u;               // 64 lines x D / 2 bytes (latent 128: 4 KiB)
+    static constexpr unsigned LDS = PSST_OFF + CGNN_W8_WAVES * PSST_BYTES;
+    static_assert(LDS <= 160u * 1024u, "LDS budget");
 };
 
 // ---- the ring -------------------------------------------------------------------------------------------------------
-// Four slots, one barrier per ring step ("interval").  In interval g waves 0-3 compute chunk g out of slot g % 4 and
-// waves 4-7 chunk g - LAG; every wave issues its pieces of chunk g + 3 - LAG into the one slot nobody reads or awaits
-// (LAG 1: slots g - 1 and g are being read, g + 1 must be complete at the interval's end; LAG 0: g, then g + 1 and
-// g + 2 in flight), waits -- counted -- for its own pieces of chunk g + 1 and meets the others at the barrier.
+// Three slots, one barrier per ring step ("interval").  In interval g waves 0-3 compute chunk g out of slot g % 3 and
+// waves 4-7 chunk g - LAG.
+//   LAG 0: every wave issues its pieces of chunk g + 2 into the slot everybody left at the last barrier, and waits --
+//          counted -- for its own pieces of chunk g + 1 (issued an interval ago) before the barrier;
+//   LAG 1: slots g - 1 and g are being read, so the pieces of chunk g + 1 go into the third one in the FIRST MFMA slots
+//          of the interval and are awaited at its end (vmcnt(0): an interval is 4-5 k cycles, an L2-warm piece lands in
+//          a few hundred).
 // Every wave issues NP pieces per chunk; where 8 NP exceeds the chunk's pieces the surplus ones repeat an earlier
 // piece (same bytes to the same place), which keeps every wave's operation count, and so every wait count, the same.
 template <class W, int LAG>
@@ -86,17 +102,16 @@ struct RingW {
     int wave, lane;
     int slot;            // of this wave's current step
     int dma_chunk, dma_slot;
+#ifdef CGNN_W8_STAMPS
+    W8Timer tm;
+#endif
     __device__ __forceinline__ RingW(const char* img, int cnt, int w, int l)
         : image(img), count(cnt), wave(w), lane(l), slot(0), dma_chunk(0), dma_slot(0) {}
     __device__ __forceinline__ unsigned lds0() const { return (unsigned)(uintptr_t)(LdsWeightPtr)(cgnn_smem); }
     __device__ __forceinline__ unsigned base() const { return lds0() + (unsigned)slot * W::STRIDE; }
     __device__ __forceinline__ unsigned vec_addr() const { return base() + W::VEC_OFF; }
     __device__ __forceinline__ unsigned lnbuf(int which) const { return lds0() + W::LNBUF_OFF + (unsigned)which * W::LNBUF_BYTES; }
-    bool primed = false;
     __device__ __forceinline__ void piece(int i) {
-#ifdef CGNN_W8_ABL_DMA
-        if (primed) return;
-#endif
         asm volatile("" ::: "memory");
 #if defined(__HIP_DEVICE_COMPILE__)      // (the host pass of hipcc does not know the buffer builtins)
         int idx = wave + CGNN_W8_WAVES * i;
@@ -112,7 +127,7 @@ struct RingW {
     }
     __device__ __forceinline__ void dma_done() {
         dma_chunk = dma_chunk + 1 == count ? 0 : dma_chunk + 1;
-        dma_slot = (dma_slot + 1) & (CGNN_W8_SLOTS - 1);
+        dma_slot = dma_slot + 1 == CGNN_W8_SLOTS ? 0 : dma_slot + 1;
     }
     __device__ __forceinline__ void prime() {
         for (int c = 0; c < CGNN_W8_SLOTS - 1 - LAG; ++c) {
@@ -122,29 +137,21 @@ struct RingW {
         CGNN_S32_VMCNT(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        primed = true;
     }
-    // End of an interval.  EXTRA = vector-memory operations other than ring pieces this wave has issued in this interval
-    // and that may still be in flight (they are newer than the pieces waited for).  A smaller count than the true one
-    // only waits longer.
-#ifdef CGNN_W8_STAMPS
-    W8Timer tm;
-#endif
-    template <int EXTRA, int K0 = 17>      // (K0: first of this call's three timer slots, developer builds)
+    // End of an interval.  EXTRA (LAG 0) = vector-memory operations other than ring pieces this wave has issued in this
+    // interval (they are newer than the pieces waited for; a smaller count than the true one only waits longer).
+    // K0: first of this call's three timer slots (developer builds).
+    template <int EXTRA, int K0 = 17>
     __device__ __forceinline__ void interval_end() {
         CGNN_W8_STAMP(K0);
-#ifndef CGNN_W8_ABL_VMWAIT
-        vm_wait_const<(2 - LAG) * W::NP + EXTRA>();
-#endif
+        vm_wait_const<(LAG ? 0 : W::NP + EXTRA)>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         CGNN_W8_STAMP(K0 + 1);
-#ifndef CGNN_W8_ABL_BARRIER     // (developer timing builds CGNN_W8_ABL_*: wrong results)
         __builtin_amdgcn_s_barrier();
-#endif
         asm volatile("" ::: "memory");
         CGNN_W8_STAMP(K0 + 2);
     }
-    __device__ __forceinline__ void advance() { slot = (slot + 1) & (CGNN_W8_SLOTS - 1); }
+    __device__ __forceinline__ void advance() { slot = slot + 1 == CGNN_W8_SLOTS ? 0 : slot + 1; }
     // an interval in which this wave computes nothing (the lagging waves' first, the leading waves' last)
     __device__ __forceinline__ void idle_interval() {
         for (int i = 0; i < W::NP; ++i) piece(i);
@@ -255,63 +262,120 @@ __device__ __forceinline__ LnStats ln_stats_w(const f32x16 (&acc)[DT]) {
     st.nmr = -mean * st.rstd;
     return st;
 }
+template <int IMM>
+__device__ __forceinline__ void lnw_vec_read(u32x4& g0, u32x4& g1, u32x4& b0, u32x4& b1, unsigned ga, unsigned ba) {
+    asm volatile("ds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %4 offset:%7\n\t"
+                 "ds_read_b128 %2, %5 offset:%6\n\tds_read_b128 %3, %5 offset:%7"
+                 : "=&v"(g0), "=&v"(g1), "=&v"(b0), "=&v"(b1)
+                 : "v"(ga), "v"(ba), "n"(IMM), "n"(IMM + 32));
+}
+template <int NEWER>
+__device__ __forceinline__ void lnw_vec_wait(u32x4& g0, u32x4& g1, u32x4& b0, u32x4& b1) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(g0), "+v"(g1), "+v"(b0), "+v"(b1) : "n"(NEWER));
+}
+// gamma / beta of a slice (eight features: two 16-byte pieces of each vector) come through two register sets filled by
+// hand-issued LDS reads, one slice ahead: left to the compiler, the reads of all slices are hoisted to the top (128
+// registers at latent 128: spills), or each slice waits out its own LDS round trip.  The caller must have no other LDS
+// reads in flight that it still counts on (lgkmcnt is shared).
 template <bool RES, int DT, int K0, int K1>
 __device__ __forceinline__ void ln_affine_w(const f32x16 (&acc)[DT], f32x16 (&ev)[DT], bf16x8 (&in)[2 * DT], unsigned lnv, int h,
                                             LnStats st) {
-    constexpr int D = 32 * DT;
-    const LdsVecPtr gp = (LdsVecPtr)(uintptr_t)lnv;
-    __builtin_amdgcn_sched_barrier(0);
-    static_for_each([&](auto kc) __attribute__((always_inline)) {
-        constexpr int k = decltype(kc)::value + K0, t = k >> 1, s = k & 1;
-#ifdef CGNN_W8_ABL_LN       // (developer timing build, wrong results: keeps the MFMAs alive)
-        packw_slice<false, DT, t, s>(in, acc);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ev[t][8 * s + i] += acc[t][8 * s + i];
+    if constexpr (K1 > K0) {
+        constexpr int D = 32 * DT;
+#if CGNN_W8_LN_ASM == 2
+        const unsigned ga = lnv + 16u * (unsigned)h, ba = ga + (unsigned)D * 4u;
+        u32x4 vg[2][2], vb[2][2];
+        lnw_vec_read<(32 * (K0 >> 1) + 16 * (K0 & 1)) * 4>(vg[K0 & 1][0], vg[K0 & 1][1], vb[K0 & 1][0], vb[K0 & 1][1], ga, ba);
+#elif CGNN_W8_LN_ASM == 1
+        const unsigned ga = lnv + 16u * (unsigned)h, ba = ga + (unsigned)D * 4u;
+        u32x4 vg[1][2], vb[1][2];
 #else
-        u32x4 v;
-#pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
-            const int g = 2 * s + gg;
-            const f32x4 gm = *(LdsVec4Ptr)(gp + 32 * t + 8 * g + 4 * h);
-            const f32x4 bt = *(LdsVec4Ptr)(gp + D + 32 * t + 8 * g + 4 * h);
-            float e[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float nrm = __builtin_fmaf(acc[t][4 * g + c], st.rstd, st.nmr);
-                const float base = RES ? bt[c] + ev[t][4 * g + c] : bt[c];
-                e[c] = __builtin_fmaf(nrm, gm[c], base);
-                ev[t][4 * g + c] = e[c];
-            }
-            v[2 * gg] = pack_bf16(e[0], e[1]);
-            v[2 * gg + 1] = pack_bf16(e[2], e[3]);
-        }
-        in[2 * t + s] = __builtin_bit_cast(bf16x8, v);
+        const LdsVecPtr gp = (LdsVecPtr)(uintptr_t)lnv;
+        __builtin_amdgcn_sched_barrier(0);
 #endif
-        __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise hoists every slice's LDS reads to the top: 128 registers)
-    }, std::make_integer_sequence<int, (K1 > K0 ? K1 - K0 : 0)>{});
+        static_for_each([&](auto kc) __attribute__((always_inline)) {
+            constexpr int k = decltype(kc)::value + K0, t = k >> 1, s = k & 1;
+#if CGNN_W8_LN_ASM == 2
+            constexpr int cur = k & 1, nxt = cur ^ 1;
+            if constexpr (k + 1 < K1) {
+                constexpr int t1 = (k + 1) >> 1, s1 = (k + 1) & 1;
+                lnw_vec_read<(32 * t1 + 16 * s1) * 4>(vg[nxt][0], vg[nxt][1], vb[nxt][0], vb[nxt][1], ga, ba);
+                lnw_vec_wait<4>(vg[cur][0], vg[cur][1], vb[cur][0], vb[cur][1]);
+            } else {
+                lnw_vec_wait<0>(vg[cur][0], vg[cur][1], vb[cur][0], vb[cur][1]);
+            }
+#elif CGNN_W8_LN_ASM == 1
+            constexpr int cur = 0;
+            lnw_vec_read<(32 * t + 16 * s) * 4>(vg[0][0], vg[0][1], vb[0][0], vb[0][1], ga, ba);
+            lnw_vec_wait<0>(vg[0][0], vg[0][1], vb[0][0], vb[0][1]);
+#endif
+#ifdef CGNN_W8_ABL_LN       // (developer timing build, wrong results: keeps the MFMAs alive)
+            packw_slice<false, DT, t, s>(in, acc);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ev[t][8 * s + i] += acc[t][8 * s + i];
+#else
+            u32x4 v;
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+                const int g = 2 * s + gg;
+#if CGNN_W8_LN_ASM
+                const f32x4 gm = __builtin_bit_cast(f32x4, vg[cur][gg]);
+                const f32x4 bt = __builtin_bit_cast(f32x4, vb[cur][gg]);
+#else
+                const f32x4 gm = *(LdsVec4Ptr)(gp + 32 * t + 8 * g + 4 * h);
+                const f32x4 bt = *(LdsVec4Ptr)(gp + D + 32 * t + 8 * g + 4 * h);
+#endif
+                float e[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float nrm = __builtin_fmaf(acc[t][4 * g + c], st.rstd, st.nmr);
+                    const float base = RES ? bt[c] + ev[t][4 * g + c] : bt[c];
+                    e[c] = __builtin_fmaf(nrm, gm[c], base);
+                    ev[t][4 * g + c] = e[c];
+                }
+                v[2 * gg] = pack_bf16(e[0], e[1]);
+                v[2 * gg + 1] = pack_bf16(e[2], e[3]);
+            }
+            in[2 * t + s] = __builtin_bit_cast(bf16x8, v);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }, std::make_integer_sequence<int, K1 - K0>{});
+    }
+}
+
+// selector MFMAs of row tiles [T0, T1): acc[t] = Ps[src] + Pd[dst] (see selp32 in s32.hpp)
+template <int DT, int T0, int T1>
+__device__ __forceinline__ void selp_rows(f32x16 (&acc)[DT], const bf16x8 (&ps)[2 * DT], const bf16x8 (&pd)[2 * DT], bf16x8 sel0,
+                                          bf16x8 sel1) {
+    static_for_each([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value + T0;
+        f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel0, ps[2 * t], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel1, ps[2 * t + 1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel0, pd[2 * t], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel1, pd[2 * t + 1], c, 0, 0, 0);
+        acc[t] = c;
+    }, std::make_integer_sequence<int, T1 - T0>{});
 }
 
 // ---- the kernel -----------------------------------------------------------------------------------------------------
 // One wave, one tile, per pass (= the encoder, or one round), NH hidden layers:
-//   first step   [pd rows requested] LayerNorm of the PREVIOUS pass (its vectors were copied aside before the barrier)
-//                selector MFMAs (Ps[src] + Pd[dst] -> accumulators) | encoder: bias
-//                layer 0: 32 MFMAs; each finished row tile is packed (ReLU) into the next operand under the next rows' MFMAs
+//   first step   the previous pass's LayerNorm affine part (its vectors were copied aside before the barrier) with the
+//                second half of the sender rows in flight; selector MFMAs (Ps[src] + Pd[dst] -> accumulators; encoder:
+//                bias); layer 0: 32 MFMAs, each finished row tile packed (ReLU) into the next operand under the next
+//                rows' MFMAs
 //   hidden steps bias, MFMAs, pack
-//   last step    bias, [ps rows of the next pass requested], MFMAs, (waves 0-3: LayerNorm vectors -> side buffer)
-// Ring pieces are spread over every step's MFMA slots; every step ends with RingW::interval_end.
-// PDB ("receiver rows broadcast"): the edge list is receiver-sorted with a fixed in-degree seg_k that divides 32 or is a
-// multiple of it (what data_utils.preprocess emits), so a tile's 32 edges have at most four receivers: their
-// Pd rows are fetched by ONE load instruction per round (every lane one 16-byte chunk), parked in LDS and read back as
-// the eight B-operand pieces with broadcast reads, instead of eight gather instructions in which sixteen lanes fetch the
-// same bytes.  Vector-memory instructions are what this kernel's waves wait on most (their issue blocks the wave).
-template <int DT, int NH, bool ENC, int LAG, bool PDB>
+//   last step    bias, MFMAs (first half of the next pass's sender rows and the receiver rows requested from their first
+//                slots), LayerNorm statistics, (waves 0-3: LayerNorm vectors -> side buffer)
+// Ring pieces go out in the first MFMA slots of every step; every step ends with RingW::interval_end.
+template <int DT, int NH, bool ENC, int LAG>
 __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
     S32Args a, const __bf16* __restrict__ ps_all, const __bf16* __restrict__ pd_all, int64_t round_stride,
     const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t num_edges, const float* e_in, float* e_out,
     const float* __restrict__ attr, int ld_attr, int seg_k) {
     typedef W8Geom<DT> W;
+    static_assert(DT == 4, "the sender-row staging is laid out for latent 128 (four lanes per 64-byte half line)");
     constexpr int D = W::D, KS = W::KS, NP = W::NP;
-    constexpr int MQ = DT * KS;                 // MFMAs (slots) of a full layer block
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool lagging = LAG != 0 && wave >= CGNN_W8_WAVES / 2;
@@ -344,39 +408,10 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
     int64_t tile = tr.first < tr.end ? tr.first : tr.end - 1;
     bool valid = tr.first < tr.end;
 
-    // P rows: lane (r, h) owns the 16-byte pieces of its half of the row; piece pc = the B operand of k-step pc
-    auto load_p = [&](bf16x8 (&p)[2 * DT], const __bf16* table, unsigned off) __attribute__((always_inline)) {
-#ifdef CGNN_W8_ABL_P
-        const u32x4 z = {off, off, off, off};
-#pragma unroll
-        for (int i = 0; i < 2 * DT; ++i) p[i] = __builtin_bit_cast(bf16x8, z);
-        return;
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(CGNN_W8_P_GLOBAL)
-        // buffer form: the round's table as the descriptor (scalar), the lane's row offset as a 32-bit vector offset, the
-        // piece as the instruction's immediate: no 64-bit vector address per lane
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(table), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < 2 * DT; ++i)
-            p[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + 16u * (unsigned)i), 0, 0));
-#else
-        const bf16x8* q = reinterpret_cast<const bf16x8*>(reinterpret_cast<const char*>(table) + off);
-#pragma unroll
-        for (int i = 0; i < 2 * DT; ++i) p[i] = q[i];
-#endif
-    };
-    auto load_p_piece = [&](const __bf16* table, unsigned off) __attribute__((always_inline)) -> bf16x8 {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(CGNN_W8_ABL_P)
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(table), 0, 0x7fffffff, 0x00020000);
-        return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0));
-#else
-        const u32x4 z = {off, off, off, off};
-        return __builtin_bit_cast(bf16x8, z);
-#endif
-    };
-    // PDB: one 16-byte chunk per lane of the tile's receiver rows -> LDS -> the eight pieces of this lane's half row
+    // ---- receiver rows: one 16-byte chunk per lane of the tile's (<= 4) receiver rows -> LDS -> the eight pieces of this
+    // lane's half row (broadcast reads)
     const unsigned pdst = ring.lds0() + W::PDST_OFF + (unsigned)wave * W::PDST_BYTES;
-    const int kk = PDB ? (seg_k < 32 ? seg_k : 32) : 32;                // edges of a tile per receiver
+    const int kk = seg_k < 32 ? seg_k : 32;                // edges of a tile per receiver
     auto load_pd_chunk = [&](const __bf16* table, unsigned off) __attribute__((always_inline)) -> u32x4 {
 #if defined(__HIP_DEVICE_COMPILE__)
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(table), 0, 0x7fffffff, 0x00020000);
@@ -388,47 +423,88 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
     auto park_pd = [&](u32x4 chunk) __attribute__((always_inline)) {
         *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(pdst + (unsigned)lane * 16u) = chunk;
     };
-    auto read_pd = [&](bf16x8 (&p)[2 * DT]) __attribute__((always_inline)) {
-        const unsigned base = pdst + ((unsigned)(r / kk) * 16u + 8u * (unsigned)h) * 16u;
+    const unsigned pd_read = pdst + ((unsigned)(r / kk) * 16u + 8u * (unsigned)h) * 16u;
+    auto read_pd = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2 * DT; ++i)
-            p[i] = __builtin_bit_cast(bf16x8, *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)(base + 16u * (unsigned)i));
+            pd[i] = __builtin_bit_cast(bf16x8, *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)(pd_read + 16u * (unsigned)i));
     };
     u32x4 pdchunk = {0u, 0u, 0u, 0u};
-    // ring pieces of this interval, spread over the M slots of a block
-    auto pieces_at = [&](auto mc, auto qc) __attribute__((always_inline)) {
-        constexpr int M = decltype(mc)::value, q = decltype(qc)::value;
-        for (int i = share_lo(NP, M, q); i < share_hi(NP, M, q); ++i) ring.piece(i);
+
+    // ---- sender rows through the staging area.  A lane's half row is one 128-byte line = pieces 0 .. 7; sub-gather SUB
+    // moves pieces 4 SUB .. 4 SUB + 3 (64 bytes) of all 64 lines: DMA instruction i, lane 4 a + j -> line 16 i + a (edge
+    // (16 i + a) % 32, half (16 i + a) / 32), piece 4 SUB + (j ^ x) with x = (a >> 2) & 3; it lands at line * 64 + j * 16,
+    // i.e. piece c of a line sits in slot c ^ x: the sixteen lanes of a ds_read_b128 group then hit sixteen different
+    // 16-byte bank groups (lines n + 32 h with n % 4 giving four 64-byte positions of a 256-byte bank row, x the slot).
+    const unsigned psst = ring.lds0() + W::PSST_OFF + (unsigned)wave * W::PSST_BYTES;
+    const unsigned ps_cq = (unsigned)((lane & 3) ^ ((lane >> 4) & 3)) * 16u;                       // this lane's piece within the quad
+    const unsigned ps_read = psst + (unsigned)(r + 32 * h) * 64u + (unsigned)((r >> 2) & 3) * 16u; // slot of piece c: ps_read ^ (c << 4)
+    unsigned so_lo = 0, so_hi = 0;      // byte offsets of the rows of edges (lane >> 2) and 16 + (lane >> 2) of the tile
+    auto stage_ps = [&](auto sub_c, auto i_c, const __bf16* table) __attribute__((always_inline)) {
+        constexpr int SUB = decltype(sub_c)::value, i = decltype(i_c)::value;
+        asm volatile("" ::: "memory");
+#if defined(__HIP_DEVICE_COMPILE__)
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(table), 0, 0x7fffffff, 0x00020000);
+        char* dstp = cgnn_smem + W::PSST_OFF + (unsigned)wave * W::PSST_BYTES + (unsigned)i * 1024u;
+        // (the constant part of the source offset travels as the scalar offset: the instruction's immediate offset is
+        // added to the LDS address as well)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsVoidPtrG)dstp, 16, ((i & 1) ? so_hi : so_lo) + ps_cq,
+                                                 (i >> 1) * D + SUB * 64, 0, 0);
+#endif
+        asm volatile("" ::: "memory");
+    };
+    auto read_ps = [&](auto sub_c) __attribute__((always_inline)) {
+        constexpr int SUB = decltype(sub_c)::value;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            ps[4 * SUB + c] = __builtin_bit_cast(
+                bf16x8, *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)(ps_read ^ ((unsigned)c << 4)));
+    };
+    // ring pieces of this interval: the first NP slots of a block
+    auto pieces_first = [&](auto qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value;
+        if constexpr (q < NP) ring.piece(q);
     };
 
+    // A tile's per-lane inputs: the sender rows' byte offsets for the staging gathers, the receiver chunk's offset and (ENC)
+    // the lane's eight edge features (k-step 0 of the encoder's operand: element j = feature 8 (j >> 2) + 4 h + (j & 3)).
+    // Loaded a whole interval ahead for the next tile (in the last block of the current one): their latency is a trip to
+    // HBM, and every wave of the workgroup would otherwise sit in it at the same time.
+    struct TileIn {      // raw loaded values: nothing is computed from them before the tile starts (a use would wait for the load)
+        int src_lo, src_hi, dst_row;
+        f32x4 q;          // ENC: the edge's (<= 4) features: one aligned 16-byte load (the launcher checks enc_in <= 4, ld_attr % 4 == 0)
+    };
+    auto load_tile_in = [&](int64_t T, TileIn& ti) __attribute__((always_inline)) {
+        const int64_t e = T * 32 + r;
+        const int64_t ce = e < num_edges ? e : num_edges - 1;
+        const int64_t e_lo = T * 32 + (lane >> 2), e_hi = e_lo + 16;
+        ti.src_lo = src[e_lo < num_edges ? e_lo : num_edges - 1];
+        ti.src_hi = src[e_hi < num_edges ? e_hi : num_edges - 1];
+        // lane l: chunk l & 15 of the row of receiver group l >> 4 (groups beyond the tile's last repeat it)
+        const int groups = 32 / kk;
+        const int j = (lane >> 4) < groups ? (lane >> 4) : groups - 1;
+        const int64_t eg = T * 32 + (int64_t)j * kk;
+        ti.dst_row = dst[eg < num_edges ? eg : num_edges - 1];
+        if (ENC) ti.q = *reinterpret_cast<const f32x4*>(attr + ce * ld_attr);
+    };
+    TileIn nxt;
+    load_tile_in(tile, nxt);
+
     for (int it = 0; it < iters; ++it) {
-        // ---- this tile's edges and inputs (compiler-tracked loads: once per tile) ----------------------------------
-        unsigned so, dof;       // byte offsets of this lane's halves of the sender / receiver P rows
-        unsigned dchunk = 0;    // PDB: byte offset of the one chunk this lane fetches of the tile's receiver rows
+        // ---- this tile's edges and inputs (requested during the previous tile's last block) ------------------------
+        // byte offset of the one chunk this lane fetches of the tile's receiver rows
+        const unsigned dchunk = (unsigned)nxt.dst_row * (unsigned)D * 2u + (unsigned)(lane & 15) * 16u;
+        const int64_t tn = tile + tr.stride;
+        const int64_t tile_next = tn < tr.end ? tn : tile;      // (a wave past its range recomputes its last tile)
         {
-            const int64_t e = tile * 32 + r;
-            const int64_t ce = e < num_edges ? e : num_edges - 1;
-            so = ((unsigned)src[ce] * (unsigned)D + (unsigned)h * (D / 2)) * 2u;
-            dof = ((unsigned)dst[ce] * (unsigned)D + (unsigned)h * (D / 2)) * 2u;
-            if constexpr (PDB) {
-                // lane l: chunk l & 15 of the row of receiver group l >> 4 (groups beyond the tile's last repeat it)
-                const int groups = 32 / kk;
-                const int j = (lane >> 4) < groups ? (lane >> 4) : groups - 1;
-                const int64_t eg = tile * 32 + (int64_t)j * kk;
-                dchunk = (unsigned)dst[eg < num_edges ? eg : num_edges - 1] * (unsigned)D * 2u + (unsigned)(lane & 15) * 16u;
-            }
-#ifdef CGNN_W8_ABL_PSAME      // every lane gathers from the same two rows: two or four cache lines per load instruction
-            so = ((unsigned)src[tile * 32 < num_edges ? tile * 32 : 0] * (unsigned)D + (unsigned)h * (D / 2)) * 2u;
-#endif
+            so_lo = (unsigned)nxt.src_lo * (unsigned)D * 2u;
+            so_hi = (unsigned)nxt.src_hi * (unsigned)D * 2u;
             if (ENC) {
-                // lane (r, h), k-step 0, element j = edge feature 8 (j >> 2) + 4 h + (j & 3)
+                // lane (r, h), k-step 0, element j = edge feature 8 (j >> 2) + 4 h + (j & 3): features 0 .. 3 sit in the h = 0 lanes
                 const int fin = a.enc_in_dim;
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int f = 8 * (j >> 2) + 4 * h + (j & 3);
-                    v[j] = f < fin ? attr[ce * ld_attr + f] : 0.f;
-                }
+                for (int jj = 0; jj < 8; ++jj) v[jj] = (jj < 4 && h == 0 && jj < fin) ? nxt.q[jj] : 0.f;
                 u32x4 w;
                 w[0] = pack_bf16(v[0], v[1]);
                 w[1] = pack_bf16(v[2], v[3]);
@@ -448,45 +524,64 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
                         for (int x = 0; x < 4; ++x) w[x] = pack_bf16(ev[t][8 * s + 2 * x], ev[t][8 * s + 2 * x + 1]);
                         inb[0][2 * t + s] = __builtin_bit_cast(bf16x8, w);
                     }
-                load_p(ps, ps_all, so);
-                if constexpr (PDB) {
-                    park_pd(load_pd_chunk(pd_all, dchunk));
-                    read_pd(pd);
-                } else {
-                    load_p(pd, pd_all, dof);
-                }
+                // round 0's P rows, synchronously (once per tile)
+                park_pd(load_pd_chunk(pd_all, dchunk));
+                static_for_each([&](auto ic) __attribute__((always_inline)) { stage_ps(CGNN_IC(0), ic, ps_all); },
+                                std::make_integer_sequence<int, 4>{});
+                CGNN_S32_VMCNT(0);
+                read_ps(CGNN_IC(0));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                static_for_each([&](auto ic) __attribute__((always_inline)) { stage_ps(CGNN_IC(1), ic, ps_all); },
+                                std::make_integer_sequence<int, 4>{});
+                CGNN_S32_VMCNT(0);
+                read_ps(CGNN_IC(1));
+                read_pd();
             }
         }
 
         // ---- the steps ---------------------------------------------------------------------------------------------
         // first step of a pass.  IS_ENC: the edge encoder (layer 0 = Linear of the edge features with bias, no P rows);
         // otherwise round rr (layer 0 = Ps[src] + Pd[dst] + We e).  PEND: LayerNorm of the previous pass still to do
-        // (0 none, 1 the encoder's, 2 a round's).  The sender rows `ps` were requested in the previous pass's last step.
+        // (0 none: the tile's first pass, its P rows are in registers; 1 the encoder's, 2 a round's).  With PEND the first
+        // half of the sender rows sits in the staging area and the receiver chunk in `pdchunk`, both requested in the
+        // previous pass's last step.
         auto step_first = [&](auto enc_tag, auto pend_tag, int rr) __attribute__((always_inline)) {
             constexpr bool IS_ENC = decltype(enc_tag)::value;
             constexpr int PEND = decltype(pend_tag)::value;
             constexpr int KS0 = IS_ENC ? 2 : KS;     // the encoder's first Linear: K padded to one 32-wide k tile
-            constexpr int M0 = DT * KS0;
             CGNN_W8_STAMP(8);
             if constexpr (PEND != 0) {
-                // the rest of the previous pass's LayerNorm (its first slices ran before the barrier, in that pass's last step)
-                if constexpr (!IS_ENC && PDB) park_pd(pdchunk);      // requested in the previous pass's last step
-                if constexpr (!IS_ENC && !PDB) load_p(pd, pd_all + (int64_t)rr * round_stride, dof);
+                if constexpr (!IS_ENC) {
+                    // the first half of the sender rows was requested behind the ring pieces of the last interval; its
+                    // LDS-DMA is invisible to the compiler's own waits (LAG 1: interval_end has already waited for it)
+                    if constexpr (LAG == 0) CGNN_S32_VMCNT(0);
+                    park_pd(pdchunk);
+                    read_ps(CGNN_IC(0));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the staging area is free again
+                    const __bf16* tps = ps_all + (int64_t)rr * round_stride;
+                    static_for_each([&](auto ic) __attribute__((always_inline)) { stage_ps(CGNN_IC(1), ic, tps); },
+                                    std::make_integer_sequence<int, 4>{});
+                }
                 ln_affine_w<PEND == 2, DT, KA, 2 * DT>(acc, ev, inb[0], ring.lnbuf(lnpar ^ 1), h, lnst);
-                if constexpr (!IS_ENC && PDB) read_pd(pd);
+                if constexpr (!IS_ENC) read_pd();
             }
             const unsigned base = ring.base();
             CGNN_W8_STAMP(9);
             if constexpr (IS_ENC) {
                 bias_rowsw<DT>(acc, ring.vec_addr(), h);
+            } else if constexpr (PEND != 0) {
+                selp_rows<DT, 0, DT / 2>(acc, ps, pd, sel0, sel1);
+                CGNN_S32_VMCNT(0);      // the second half of the sender rows (requested a LayerNorm ago; nothing newer in flight)
+                read_ps(CGNN_IC(1));
+                selp_rows<DT, DT / 2, DT>(acc, ps, pd, sel0, sel1);
             } else {
-                selp32<DT>(acc, ps, pd, sel0, sel1, NoFill32{});
+                selp_rows<DT, 0, DT>(acc, ps, pd, sel0, sel1);
             }
             CGNN_W8_STAMP(10);
             const bf16x8 (&in0)[KS0] = reinterpret_cast<const bf16x8(&)[KS0]>(inb[0][0]);
             wblockw<DT, KS0>(acc, in0, base, make_fill([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value, t = q / KS0 - 1, w = q % KS0;
-                pieces_at(CGNN_IC(M0), qc);
+                pieces_first(qc);
                 if constexpr (t >= 0 && w == (KS0 > 2 ? 1 : KS0 - 1)) packw_slice<true, DT, (t < 0 ? 0 : t), 0>(inb[1], acc);
                 if constexpr (t >= 0 && w == (KS0 > 4 ? 3 : KS0 - 1)) packw_slice<true, DT, (t < 0 ? 0 : t), 1>(inb[1], acc);
             }));
@@ -497,13 +592,13 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
             ring.advance();
         };
         // hidden layer l (1 .. NH - 1)
-        auto step_hidden = [&](auto lc, int rr) __attribute__((always_inline)) {
+        auto step_hidden = [&](auto lc) __attribute__((always_inline)) {
             constexpr int l = decltype(lc)::value;
             CGNN_W8_STAMP(14);
             bias_rowsw<DT>(acc, ring.vec_addr(), h);
             wblockw<DT, KS>(acc, inb[l & 1], ring.base(), make_fill([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value, t = q / KS - 1, w = q % KS;
-                pieces_at(CGNN_IC(MQ), qc);
+                pieces_first(qc);
                 if constexpr (t >= 0 && w == (KS > 2 ? 1 : KS - 1)) packw_slice<true, DT, (t < 0 ? 0 : t), 0>(inb[(l + 1) & 1], acc);
                 if constexpr (t >= 0 && w == (KS > 4 ? 3 : KS - 1)) packw_slice<true, DT, (t < 0 ? 0 : t), 1>(inb[(l + 1) & 1], acc);
             }));
@@ -513,26 +608,25 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
             ring.template interval_end<0, 15>();
             ring.advance();
         };
-        // output layer; WITH_PS: request the next pass's sender rows (table `nps`) first
-        auto step_last = [&](auto ps_tag, auto res_tag, const __bf16* nps, const __bf16* npd, int rr) __attribute__((always_inline)) {
-            constexpr bool WITH_PS = decltype(ps_tag)::value, RES = decltype(res_tag)::value;
+        // output layer; WITH_P: request the next pass's P rows (tables nps / npd) from the slots behind the ring pieces
+        auto step_last = [&](auto p_tag, auto res_tag, const __bf16* nps, const __bf16* npd) __attribute__((always_inline)) {
+            constexpr bool WITH_P = decltype(p_tag)::value, RES = decltype(res_tag)::value;
             CGNN_W8_STAMP(0);
             bias_rowsw<DT>(acc, ring.vec_addr(), h);
             CGNN_W8_STAMP(1);
-            // the next pass's P rows are requested one instruction per MFMA slot (a burst of nine loads per wave fills the
-            // memory pipeline's queues: the waves dispatched second then wait thousands of cycles to issue theirs)
             wblockw<DT, KS>(acc, inb[NH & 1], ring.base(), make_fill([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value;
-                if constexpr (WITH_PS && q < 2 * DT) ps[q] = load_p_piece(nps, so + 16u * (unsigned)q);
-                if constexpr (WITH_PS && PDB && q == 2 * DT) pdchunk = load_pd_chunk(npd, dchunk);
-                if constexpr (q > 2 * DT) pieces_at(CGNN_IC(MQ - 2 * DT - 1), CGNN_IC(q - 2 * DT - 1));
+                pieces_first(qc);
+                if constexpr (WITH_P && q >= NP && q < NP + 4) stage_ps(CGNN_IC(0), CGNN_IC(q - NP), nps);
+                if constexpr (WITH_P && q == NP + 4) pdchunk = load_pd_chunk(npd, dchunk);
+                if constexpr (!WITH_P && q == NP) load_tile_in(tile_next, nxt);      // the tile's last block: the next tile's inputs
             }));
             CGNN_W8_STAMP(2);
-            // LayerNorm: statistics and the first KA slices here, under the partner wave's matrix work of this interval; the
-            // rest behind the barrier (balances the two intervals' vector work when the partner runs a layer behind)
+            // LayerNorm: the statistics and the first KA affine slices here (vectors straight from this chunk), the rest behind
+            // the barrier: with LAG 1 this balances the vector work of the two intervals a pass boundary touches
             lnst = ln_stats_w<DT>(acc);
             ln_affine_w<RES, DT, 0, KA>(acc, ev, inb[0], ring.vec_addr() + (unsigned)D * 4u, h, lnst);
-            // the LayerNorm vectors of this chunk, for the slices that run in the next interval (when this slot may
+            // the LayerNorm vectors of this chunk, for the affine part that runs in the next interval (when this slot may
             // already be refilled): waves 0-3 copy gamma | beta (2 D floats) aside
             if (wave < CGNN_W8_WAVES / 2) {
                 const int idx = wave * 64 + lane;
@@ -544,35 +638,34 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
             }
             lnpar ^= 1;
             ring.dma_done();
-            ring.template interval_end<(WITH_PS ? 2 * DT + (PDB ? 1 : 0) : 0), 3>();
+            ring.template interval_end<(WITH_P ? 5 : 4), 3>();      // (the next tile's inputs: at least four loads)
             ring.advance();
         };
-        auto hidden_steps = [&](int rr) __attribute__((always_inline)) {
+        auto hidden_steps = [&]() __attribute__((always_inline)) {
             static_for_each([&](auto lc) __attribute__((always_inline)) {
-                step_hidden(std::integral_constant<int, decltype(lc)::value + 1>{}, rr);
+                step_hidden(std::integral_constant<int, decltype(lc)::value + 1>{});
             }, std::make_integer_sequence<int, NH - 1>{});
         };
 
         if (ENC) {
             step_first(std::true_type{}, CGNN_IC(0), 0);
-            hidden_steps(-1);
-            step_last(std::true_type{}, std::false_type{}, ps_all, pd_all, -1);
+            hidden_steps();
+            step_last(std::true_type{}, std::false_type{}, ps_all, pd_all);
             step_first(std::false_type{}, CGNN_IC(1), 0);
-            hidden_steps(0);
+            hidden_steps();
         } else {
             step_first(std::false_type{}, CGNN_IC(0), 0);
-            hidden_steps(0);
+            hidden_steps();
         }
         for (int rr = 1; rr < L; ++rr) {
-            step_last(std::true_type{}, std::true_type{}, ps_all + (int64_t)rr * round_stride, pd_all + (int64_t)rr * round_stride, rr);
+            step_last(std::true_type{}, std::true_type{}, ps_all + (int64_t)rr * round_stride, pd_all + (int64_t)rr * round_stride);
             step_first(std::false_type{}, CGNN_IC(2), rr);
-            hidden_steps(rr);
+            hidden_steps();
         }
-        step_last(std::false_type{}, std::true_type{}, ps_all, pd_all, -1);
+        step_last(std::false_type{}, std::true_type{}, ps_all, pd_all);
         ln_affine_w<true, DT, KA, 2 * DT>(acc, ev, inb[0], ring.lnbuf(lnpar ^ 1), h, lnst);
 
         if (valid) store_tile<DT>(ev, e_out + tile * (32 * D), lane);
-        const int64_t tn = tile + tr.stride;
         if (tn < tr.end) {
             tile = tn;
         } else {
@@ -588,13 +681,13 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
     __builtin_amdgcn_s_barrier();
 }
 
-template <int DT, int NH, int LAG, bool PDB>
+template <int DT, int NH, int LAG>
 static int launch_w8(const S32Args& a, const __bf16* ps, const __bf16* pd, int64_t round_stride, const int32_t* src,
                      const int32_t* dst, int64_t num_edges, const float* e_in, float* e_out, const float* attr, int ld_attr,
                      int seg_k, hipStream_t st) {
     typedef W8Geom<DT> W;
     const bool enc = a.enc_in_dim > 0;
-    auto kern = enc ? edge_stream32w_kernel<DT, NH, true, LAG, PDB> : edge_stream32w_kernel<DT, NH, false, LAG, PDB>;
+    auto kern = enc ? edge_stream32w_kernel<DT, NH, true, LAG> : edge_stream32w_kernel<DT, NH, false, LAG>;
     static bool attr_set[2][16] = {};      // per (kernel, device): the attribute is sticky, setting it costs a driver call per launch
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
@@ -647,8 +740,9 @@ static int launch_w8(const S32Args& a, const __bf16* ps, const __bf16* pd, int64
 
 using namespace cgnn;
 
-extern "C" int cgnn_edge_stream_w8_supported(int32_t latent, int32_t num_hidden_layers) {
-    return (latent == 128 && num_hidden_layers >= 1 && num_hidden_layers <= 3) ? 1 : 0;
+extern "C" int cgnn_edge_stream_w8_supported(int32_t latent, int32_t num_hidden_layers, int32_t fixed_k) {
+    const bool k_ok = fixed_k >= 8 && (fixed_k <= 32 ? 32 % fixed_k == 0 : fixed_k % 32 == 0);
+    return (latent == 128 && num_hidden_layers >= 1 && num_hidden_layers <= 3 && k_ok) ? 1 : 0;
 }
 
 extern "C" int cgnn_edge_stream_run_w8(const void* image, size_t image_bytes, int32_t latent, int32_t num_hidden_layers,
@@ -661,13 +755,16 @@ extern "C" int cgnn_edge_stream_run_w8(const void* image, size_t image_bytes, in
         set_error("cgnn_edge_stream_run_w8: invalid argument");
         return CGNN_ERR_INVALID_ARG;
     }
-    if (enc_in_dim > 16) {
-        set_error("cgnn_edge_stream_run_w8: the in-launch encoder takes at most 16 edge features (got %d)", enc_in_dim);
+    if (enc_in_dim > 4 || (enc_in_dim > 0 && ((ld_attr & 3) != 0 || ((uintptr_t)edge_attr & 15) != 0))) {
+        set_error("cgnn_edge_stream_run_w8: the in-launch encoder reads an edge's features with one aligned 16-byte load: at most "
+                  "4 features (got %d), ld_attr a multiple of 4 (got %d), edge_attr 16-byte aligned; other layouts: "
+                  "cgnn_edge_stream_run", enc_in_dim, ld_attr);
         return CGNN_ERR_UNSUPPORTED;
     }
-    if (!cgnn_edge_stream_w8_supported(latent, num_hidden_layers)) {
-        set_error("cgnn_edge_stream_run_w8: no kernel for latent=%d with %d hidden layers (built for latent 128, 1..3 hidden "
-                  "layers of the same width)", latent, num_hidden_layers);
+    if (!cgnn_edge_stream_w8_supported(latent, num_hidden_layers, fixed_k) || num_edges % fixed_k != 0) {
+        set_error("cgnn_edge_stream_run_w8: no kernel for latent=%d, %d hidden layers, fixed_k=%d on %lld edges (built for latent "
+                  "128, 1..3 hidden layers of the same width and receiver-sorted edge lists of fixed in-degree 8, 16, 32, 64, ...; "
+                  "other shapes: cgnn_edge_stream_run)", latent, num_hidden_layers, fixed_k, (long long)num_edges);
         return CGNN_ERR_UNSUPPORTED;
     }
     const size_t need = cgnn_edge_stream_image_bytes(latent, num_hidden_layers, num_rounds, enc_in_dim > 0);
@@ -682,14 +779,9 @@ extern "C" int cgnn_edge_stream_run_w8(const void* image, size_t image_bytes, in
     a.nh = num_hidden_layers;
     a.enc_in_dim = enc_in_dim > 0 ? enc_in_dim : 0;
     hipStream_t st = (hipStream_t)stream;
-    // receiver rows by broadcast where a tile of 32 edges holds whole receivers (or one receiver holds whole tiles)
-    const bool pdb = fixed_k > 0 && num_edges % fixed_k == 0 && (fixed_k <= 32 ? (32 % fixed_k == 0 && fixed_k >= 8) : fixed_k % 32 == 0);
-    const int seg_k = pdb ? fixed_k : 0;
-#define CGNN_W8_GO(NHx, LAGx)                                                                                              \
-    return pdb ? launch_w8<4, NHx, LAGx, true>(a, (const __bf16*)ps_all, (const __bf16*)pd_all, round_stride, src, dst,     \
-                                               num_edges, e_in, e_out, edge_attr, ld_attr, seg_k, st)                      \
-               : launch_w8<4, NHx, LAGx, false>(a, (const __bf16*)ps_all, (const __bf16*)pd_all, round_stride, src, dst,    \
-                                                num_edges, e_in, e_out, edge_attr, ld_attr, seg_k, st)
+#define CGNN_W8_GO(NHx, LAGx)                                                                                                \
+    return launch_w8<4, NHx, LAGx>(a, (const __bf16*)ps_all, (const __bf16*)pd_all, round_stride, src, dst, num_edges, e_in, \
+                                   e_out, edge_attr, ld_attr, fixed_k, st)
     if (lag) {
         switch (num_hidden_layers) {
             case 1: CGNN_W8_GO(1, 1);

@@ -611,7 +611,7 @@ class EncodeProcessDecode(nn.Module):
             keep = {} if (want_latents and getattr(self, "keep_stream_inputs", False)) else None
             if fuse:
                 w8 = (image is not None and self.edge_stream_kernel == "tile32w" and
-                      ops.stream_w8_supported(image.latent, image.nh))
+                      ops.stream_w8_supported(image.latent, image.nh, fixed_k) and src.numel() % max(fixed_k, 1) == 0)
                 xl, el = _run_rounds_fused(rounds, xl, el, src, dst, fixed_k, agg,
                                            P["enc_edge"] if enc_in_stream else None, edge_attr, image, keep,
                                            "tile32w" if w8 else "tile32", int(getattr(self, "edge_stream_lag", 1)))

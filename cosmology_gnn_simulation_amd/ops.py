@@ -371,9 +371,10 @@ class StreamImage:
         self._keep = (list(mlps), encoder)     # the copies are asynchronous: keep the sources alive
 
 
-def stream_w8_supported(latent: int, nh: int) -> bool:
-    """Whether ``cgnn_edge_stream_run_w8`` (two waves per SIMD) is built for this shape."""
-    return bool(_lib.load().cgnn_edge_stream_w8_supported(latent, nh))
+def stream_w8_supported(latent: int, nh: int, fixed_k: int) -> bool:
+    """Whether ``cgnn_edge_stream_run_w8`` (two waves per SIMD) is built for this shape and in-degree (receiver-sorted
+    edge lists of fixed in-degree ``fixed_k``; 0 = any other edge list: not supported)."""
+    return bool(_lib.load().cgnn_edge_stream_w8_supported(latent, nh, int(fixed_k)))
 
 
 def edge_stream_run(image: StreamImage, ps_all: torch.Tensor, pd_all: torch.Tensor, src: torch.Tensor, dst: torch.Tensor,
@@ -384,7 +385,8 @@ def edge_stream_run(image: StreamImage, ps_all: torch.Tensor, pd_all: torch.Tens
     tables in ``CGNN_P_BF16_S32`` format.  When the image starts with the encoder the initial latents come from
     ``edge_attr`` and ``e_in`` is ignored.  ``kernel``: ``"tile32"`` = ``cgnn_edge_stream_run`` (one wave per SIMD, two
     tiles per wave), ``"tile32w"`` = ``cgnn_edge_stream_run_w8`` (two waves per SIMD, one tile each; ``lag`` and
-    ``fixed_k`` as in include/cgnn.h: pass the graph's fixed in-degree only when ``dst[e] == e // fixed_k``)."""
+    ``fixed_k`` as in include/cgnn.h: the graph's fixed in-degree, ``dst[e] == e // fixed_k``; see
+    ``stream_w8_supported``)."""
     if kernel not in ("tile32", "tile32w"):
         raise CgnnError(f"edge_stream_run: unknown kernel {kernel!r}")
     src, dst = i32c(src, "src"), i32c(dst, "dst")

@@ -259,13 +259,13 @@ int cgnn_edge_stream_run(const void* image, size_t image_bytes, int32_t latent, 
 /* ---- the same, third generation: 32 edges per MFMA tile, TWO waves per SIMD, one tile per wave ----------------------
  * Same image, tables, layouts and arithmetic as cgnn_edge_stream_run (reference graph_network.py:57,:89-90,:182); the
  * two co-resident waves of a SIMD overlap one's vector work (bf16 pack, LayerNorm) with the other's matrix work in
- * hardware.  lag = 1: the second wave of every SIMD runs one layer behind the first (their LayerNorms never coincide),
- * lag = 0: in step.  Results do not depend on lag.  fixed_k > 0: the caller guarantees dst[e] == e / fixed_k (receiver-
- * sorted, fixed in-degree: the layout of data_utils.preprocess, as for cgnn_aggregate); for fixed_k in {8, 16, 32, 64, ...}
- * a tile's receiver rows are then fetched once and broadcast (same results); 0: any edge list.
- * Built for hidden == latent == 128 and 1..3 hidden layers
- * (cgnn_edge_stream_w8_supported); other shapes: cgnn_edge_stream_run. */
-int cgnn_edge_stream_w8_supported(int32_t latent, int32_t num_hidden_layers);
+ * hardware, and the P rows travel through LDS (whole cache lines per load instruction).  For the graphs
+ * data_utils.preprocess emits: fixed_k = the fixed in-degree, the caller guarantees dst[e] == e / fixed_k (receiver-sorted;
+ * as for cgnn_aggregate), fixed_k in {8, 16, 32, 64, 96, ...}, latent == hidden == 128, 1..3 hidden layers
+ * (cgnn_edge_stream_w8_supported); every other shape or edge list: cgnn_edge_stream_run.
+ * lag = 1: the second wave of every SIMD runs one layer behind the first (their LayerNorms never coincide), 0: in step;
+ * results do not depend on lag. */
+int cgnn_edge_stream_w8_supported(int32_t latent, int32_t num_hidden_layers, int32_t fixed_k);
 int cgnn_edge_stream_run_w8(const void* image, size_t image_bytes, int32_t latent, int32_t num_hidden_layers,
                             int32_t num_rounds, int32_t enc_in_dim, const void* ps_all, const void* pd_all,
                             int64_t round_stride, const int32_t* src, const int32_t* dst, int64_t num_edges,

@@ -86,8 +86,15 @@ def _emulate(src, dst, ps, pd, mlps, enc, attr, e0):
 KERNELS = [("tile32", 0), ("tile32w", 0), ("tile32w", 1)]      # (kernel, lag): see ops.edge_stream_run
 
 
-def _kernel_applies(kernel, d, nh):
-    return kernel == "tile32" or ops.stream_w8_supported(d, nh)
+def _kernel_applies(kernel, d, nh, k, ragged):
+    """The two-waves-per-SIMD kernel takes the receiver-sorted fixed-k edge lists data_utils.preprocess emits."""
+    return kernel == "tile32" or (ragged == 0 and ops.stream_w8_supported(d, nh, k))
+
+
+def _fixed_k(prob, n, k):
+    """The same problem on a receiver-sorted edge list of fixed in-degree k (dst[e] == e // k)."""
+    src, dst, ps, pd, mlps, enc, attr, e0 = prob
+    return (src, torch.arange(n, dtype=torch.int32, device=DEV).repeat_interleave(k), ps, pd, mlps, enc, attr, e0)
 
 
 def _run(src, dst, ps, pd, mlps, enc, attr, e0, kernel=("tile32", 0), fixed_k=0):
@@ -113,7 +120,10 @@ CASES = [
     (700, 8, 64, 1, 12, False, 0),
     (900, 16, 32, 2, 3, True, 7),
     (333, 8, 32, 3, 6, False, 0),
+    (1000, 32, 128, 2, 2, False, 0),        # one receiver per tile
+    (150, 64, 128, 2, 2, True, 0),          # two tiles per receiver
     (14000, 16, 128, 2, 2, True, 0),        # 224,000 edges: several pairs per wave, uneven iteration counts
+    (9000, 16, 128, 2, 3, False, 0),
     (9000, 16, 128, 2, 3, False, 11),
     (20000, 8, 64, 2, 2, True, 9),
 ]
@@ -122,10 +132,13 @@ CASES = [
 @pytest.mark.parametrize("kernel", KERNELS, ids=lambda kk: f"{kk[0]}-lag{kk[1]}")
 @pytest.mark.parametrize("n,k,d,nh,rounds,with_enc,ragged", CASES)
 def test_edge_stream_run_matches_bf16_emulation(n, k, d, nh, rounds, with_enc, ragged, kernel):
-    if not _kernel_applies(kernel[0], d, nh):
-        pytest.skip("the two-waves-per-SIMD kernel is built for latent 128")
+    if not _kernel_applies(kernel[0], d, nh, k, ragged):
+        pytest.skip("the two-waves-per-SIMD kernel is built for latent 128 and fixed in-degrees 8, 16, 32, ...")
     prob = _problem(1000 + n + d + rounds, n, k, d, nh, rounds, with_enc, ragged)
-    got = _run(*prob, kernel=kernel)
+    fixed_k = 0
+    if kernel[0] == "tile32w":
+        prob, fixed_k = _fixed_k(prob, n, k), k
+    got = _run(*prob, kernel=kernel, fixed_k=fixed_k)
     want = _emulate(*prob)
     assert got.shape == want.shape
     scale = float(want.abs().max())
@@ -138,41 +151,43 @@ def test_edge_stream_run_matches_bf16_emulation(n, k, d, nh, rounds, with_enc, r
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=lambda kk: f"{kk[0]}-lag{kk[1]}")
 def test_edge_stream_run_is_deterministic_and_in_place(kernel):
-    prob = _problem(5, 5000, 16, 128, 2, 4, False)
-    a = _run(*prob, kernel=kernel)
-    b = _run(*prob, kernel=kernel)
+    prob = _fixed_k(_problem(5, 5000, 16, 128, 2, 4, False), 5000, 16)
+    fk = 16 if kernel[0] == "tile32w" else 0
+    a = _run(*prob, kernel=kernel, fixed_k=fk)
+    b = _run(*prob, kernel=kernel, fixed_k=fk)
     assert torch.equal(a, b)
     src, dst, ps, pd, mlps, enc, attr, e0 = prob
     packed = [ops.PackedMLP([(lin[0][0], None)] + lin[1:], ln, "bf16") for lin, ln in mlps]
     image = ops.StreamImage(packed, None)
     e = ops.TiledRows.from_rows(e0)
-    ops.edge_stream_run(image, _s32_table(ps), _s32_table(pd), src, dst, e, e, kernel=kernel[0], lag=kernel[1])   # e_out aliases e_in
+    ops.edge_stream_run(image, _s32_table(ps), _s32_table(pd), src, dst, e, e, kernel=kernel[0], lag=kernel[1], fixed_k=fk)   # e_out aliases e_in
     assert torch.equal(e.to_rows(), a)
 
 
 @pytest.mark.parametrize("k", [8, 16, 32, 64])
-@pytest.mark.parametrize("lag", [0, 1])
-def test_receiver_rows_by_broadcast_on_fixed_k_graphs(k, lag):
-    """The layout data_utils.preprocess emits (dst[e] == e // k): cgnn_edge_stream_run_w8 fetches a tile's receiver rows once
-    and broadcasts them through LDS.  Same P values through the same MFMAs: bit-equal to the gathering path, and equal to
-    the emulation."""
+def test_two_waves_per_simd_kernel_on_every_supported_in_degree(k):
+    """k = 8: four receivers per 32-edge tile ... k = 64: two tiles per receiver (sender rows through the LDS staging area,
+    receiver rows broadcast); against the emulation and against the one-wave-per-SIMD kernel (same bf16 P values, same
+    weights: rounding-level agreement)."""
     n = 20000 // k
     for enc in (True, False):
-        src, dst, ps, pd, mlps, encw, attr, e0 = _problem(70 + k, n, k, 128, 2, 3, enc)
-        dst = torch.arange(n, dtype=torch.int32, device=DEV).repeat_interleave(k)
-        prob = (src, dst, ps, pd, mlps, encw, attr, e0)
-        got = _run(*prob, kernel=("tile32w", lag), fixed_k=k)
-        assert torch.equal(got, _run(*prob, kernel=("tile32w", lag), fixed_k=0))
+        prob = _fixed_k(_problem(70 + k, n, k, 128, 2, 3, enc), n, k)
+        got = _run(*prob, kernel=("tile32w", 1), fixed_k=k)
         want = _emulate(*prob)
         assert float((got - want).abs().max()) <= 1e-2 * float(want.abs().max())
         assert float((got - want).norm() / want.norm()) <= 1e-3
+        other = _run(*prob, kernel=("tile32", 0))
+        assert float((got - other).norm() / other.norm()) <= 1e-3
+    with pytest.raises(ops.CgnnError):       # not a supported in-degree: the caller must take cgnn_edge_stream_run
+        _run(*_fixed_k(_problem(3, 100, 12, 128, 2, 2, False), 100, 12), kernel=("tile32w", 1), fixed_k=12)
+    assert not ops.stream_w8_supported(128, 2, 0) and not ops.stream_w8_supported(64, 2, 16)
 
 
 def test_two_waves_per_simd_kernel_does_not_depend_on_the_lag():
     """lag only shifts WHEN the second wave of a SIMD runs a layer: same arithmetic per tile, same bits."""
     for seed, enc in ((7, True), (8, False)):
-        prob = _problem(seed, 9000, 16, 128, 2, 3, enc, 5)
-        assert torch.equal(_run(*prob, kernel=("tile32w", 0)), _run(*prob, kernel=("tile32w", 1)))
+        prob = _fixed_k(_problem(seed, 9000, 16, 128, 2, 3, enc), 9000, 16)
+        assert torch.equal(_run(*prob, kernel=("tile32w", 0), fixed_k=16), _run(*prob, kernel=("tile32w", 1), fixed_k=16))
 
 
 def test_edge_stream_run_one_round_at_a_time_equals_all_rounds():
