@@ -62,6 +62,9 @@ def parse_args():
     p.add_argument("--message-source", default="x_j", choices=["x_j", "edge"])
     p.add_argument("--no-fuse-rounds", action="store_true",
                    help="x_j mode: one edge-kernel launch per round instead of cgnn_edge_stream (all rounds in one launch)")
+    p.add_argument("--edge-stream-kernel", default="tile32w", choices=["tile32w", "tile32", "tile16"],
+                   help="one-launch edge stream: tile32w = two waves per SIMD (latent 128, fixed-k graphs; other shapes take "
+                        "tile32), tile32 = one wave per SIMD with two tiles, tile16 = the first generation")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-particles", type=int, default=16384, help="bounded CPU-baseline sample size")
     p.add_argument("--cpu-threads", type=int, default=None, help="host threads for the CPU baseline (default: all)")
@@ -278,6 +281,7 @@ def main():
     model.edge_precision, model.node_precision = args.edge_precision, args.node_precision
     model.message_source = args.message_source
     model.fuse_rounds = not args.no_fuse_rounds
+    model.edge_stream_kernel = args.edge_stream_kernel
 
     dist_ctx = None
     if world > 1:
@@ -351,7 +355,8 @@ def main():
             elapsed = time.perf_counter() - t0
         per_op = tm.summary()
         packed_now = model._packed[1] if getattr(model, "_packed", None) else {}
-        stream_kernel = ("cgnn::edge_stream32_kernel" if packed_now.get("image") is not None else
+        stream_kernel = ("cgnn::edge_stream32w_kernel" if packed_now.get("image_w8") is not None else
+                         "cgnn::edge_stream32_kernel" if packed_now.get("image") is not None else
                          "cgnn::edge_stream_n16_kernel")
         # BASELINE.md section 2 asks for the median of >= 10 synchronised iterations: measured next to the contract's
         # K back-to-back steps (which `value` comes from), one device synchronisation per iteration

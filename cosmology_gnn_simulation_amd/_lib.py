@@ -37,7 +37,7 @@ EXPORTS = (
     "cgnn_mlp_backward", "cgnn_weight_grad", "cgnn_weight_grad_x3_workspace_bytes", "cgnn_weight_grad_x3",
     "cgnn_col_dot", "cgnn_col_dot2", "cgnn_csr_workspace_bytes", "cgnn_csr_build",
     "cgnn_aggregate_csr", "cgnn_aggregate_csr_add", "cgnn_edge_stream", "cgnn_edge_stream_image_bytes", "cgnn_edge_stream_image_build",
-    "cgnn_edge_stream_run", "cgnn_edge_stream_w8_supported", "cgnn_edge_stream_run_w8", "cgnn_aggregate_plan_bytes", "cgnn_aggregate_plan_build", "cgnn_aggregate_planned",
+    "cgnn_edge_stream_run", "cgnn_edge_stream_w8_supported", "cgnn_edge_stream_image_build_w8", "cgnn_edge_stream_run_w8", "cgnn_aggregate_plan_bytes", "cgnn_aggregate_plan_build", "cgnn_aggregate_planned",
 )
 ROWS, TILED32 = 0, 1
 
@@ -94,6 +94,7 @@ def load() -> C.CDLL:
     lib.cgnn_edge_stream_image_build.argtypes = [C.POINTER(Mlp), i32, C.POINTER(Mlp), i32, vp, sz, vp]
     lib.cgnn_edge_stream_run.argtypes = [vp, sz, i32, i32, i32, i32, vp, vp, i64, vp, vp, i64, vp, vp, vp, i32, vp]
     lib.cgnn_edge_stream_w8_supported.argtypes = [i32, i32, i32]
+    lib.cgnn_edge_stream_image_build_w8.argtypes = [C.POINTER(Mlp), i32, C.POINTER(Mlp), i32, vp, sz, vp]
     lib.cgnn_edge_stream_run_w8.argtypes = [vp, sz, i32, i32, i32, i32, vp, vp, i64, vp, vp, i64, vp, vp, vp, i32, i32, i32, vp]
     lib.cgnn_aggregate.argtypes = [vp, i32, vp, vp, i64, i32, i64, i32, vp, vp]
     lib.cgnn_aggregate_plan_bytes.restype = sz

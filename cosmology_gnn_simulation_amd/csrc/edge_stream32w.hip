@@ -42,9 +42,6 @@ namespace cgnn {
 #ifndef CGNN_W8_LN_EARLY
 #define CGNN_W8_LN_EARLY 0    // LayerNorm affine slices (of 2 * latent / 32) done in the output layer's own step, before the barrier
 #endif
-#ifndef CGNN_W8_LN_ASM
-#define CGNN_W8_LN_ASM 0      // LayerNorm's gamma / beta: 0 = plain LDS loads, 1 = hand-issued per slice, 2 = hand-issued one slice ahead
-#endif
 #ifndef CGNN_W8_PD
 #define CGNN_W8_PD 1       // groups in flight ahead of the MFMAs
 #endif
@@ -213,12 +210,12 @@ __device__ __forceinline__ void packw_slice(bf16x8 (&out)[2 * DT], const f32x16 
     out[2 * T + S] = RELU ? relu_bf16(b) : b;
 }
 
-// acc[t] = bias rows (plain LDS loads from the chunk's vector block)
-template <int DT>
+// acc[t] = bias rows, t in [T0, T1) (plain LDS loads from a chunk's vector block)
+template <int DT, int T0, int T1>
 __device__ __forceinline__ void bias_rowsw(f32x16 (&acc)[DT], unsigned vec_addr, int h) {
     const LdsVecPtr b = (LdsVecPtr)(uintptr_t)vec_addr;
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+    for (int t = T0; t < T1; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 v = *(LdsVec4Ptr)(b + 32 * t + 8 * g + 4 * h);
@@ -229,7 +226,7 @@ __device__ __forceinline__ void bias_rowsw(f32x16 (&acc)[DT], unsigned vec_addr,
 
 // LayerNorm (eps 1e-5, biased variance, affine) of acc over the 32 DT features of each edge (edge = lane & 31, the
 // other half of its features in lane ^ 32), in two parts so that a ring barrier can sit between them:
-//   ln_stats_w   one pass over the accumulator: sum and sum of squares (var = E[x^2] - mean^2 in f32: exact to ~1e-7
+//   ln_sums_*    one pass over the accumulator: sum and sum of squares (var = E[x^2] - mean^2 in f32: exact to ~1e-7
 //                (1 + mean^2 / var), far below the bf16 operands of this path while |mean| stays within ~100 standard
 //                deviations; the centred two-pass form costs 64 more vector instructions per tile and round);
 //   ln_affine_w  slices [K0, K1) of 2 DT: eight values each (registers 8 s .. 8 s + 7 of row tile t, k = 2 t + s):
@@ -238,77 +235,62 @@ __device__ __forceinline__ void bias_rowsw(f32x16 (&acc)[DT], unsigned vec_addr,
 struct LnStats {
     float rstd, nmr;      // normalised value = x * rstd + nmr
 };
-template <int DT>
-__device__ __forceinline__ LnStats ln_stats_w(const f32x16 (&acc)[DT]) {
-    constexpr int D = 32 * DT;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+struct LnSums {           // partial sums of a row's values and squares (four independent chains each)
+    float s[4], q[4];
+};
+__device__ __forceinline__ void ln_sums_clear(LnSums& a) {
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+    for (int i = 0; i < 4; ++i) a.s[i] = a.q[i] = 0.f;
+}
+// registers [8 S, 8 S + 8) of row tile T join the sums: 16 vector instructions, placed by the caller (behind the MFMAs
+// of the NEXT row tile, whose matrix time covers them and the wait for this row tile's last MFMA)
+template <int DT, int T, int S>
+__device__ __forceinline__ void ln_sums_add(LnSums& a, const f32x16 (&acc)[DT]) {
 #pragma unroll
-        for (int i = 0; i < 16; i += 4) {
-            s0 += acc[t][i];
-            s1 += acc[t][i + 1];
-            s2 += acc[t][i + 2];
-            s3 += acc[t][i + 3];
-            q0 = __builtin_fmaf(acc[t][i], acc[t][i], q0);
-            q1 = __builtin_fmaf(acc[t][i + 1], acc[t][i + 1], q1);
-            q2 = __builtin_fmaf(acc[t][i + 2], acc[t][i + 2], q2);
-            q3 = __builtin_fmaf(acc[t][i + 3], acc[t][i + 3], q3);
+    for (int i = 8 * S; i < 8 * S + 8; i += 4) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            a.s[c] += acc[T][i + c];
+            a.q[c] = __builtin_fmaf(acc[T][i + c], acc[T][i + c], a.q[c]);
         }
-    const float mean = half_swap_sum((s0 + s1) + (s2 + s3)) * (1.0f / D);
-    const float ex2 = half_swap_sum((q0 + q1) + (q2 + q3)) * (1.0f / D);
+    }
+}
+template <int DT>
+__device__ __forceinline__ LnStats ln_stats_finish(const LnSums& a) {
+    constexpr int D = 32 * DT;
+    const float mean = half_swap_sum((a.s[0] + a.s[1]) + (a.s[2] + a.s[3])) * (1.0f / D);
+    const float ex2 = half_swap_sum((a.q[0] + a.q[1]) + (a.q[2] + a.q[3])) * (1.0f / D);
     LnStats st;
     st.rstd = __builtin_amdgcn_rsqf(__builtin_fmaxf(__builtin_fmaf(-mean, mean, ex2), 0.f) + 1e-5f);
     st.nmr = -mean * st.rstd;
     return st;
 }
-template <int IMM>
-__device__ __forceinline__ void lnw_vec_read(u32x4& g0, u32x4& g1, u32x4& b0, u32x4& b1, unsigned ga, unsigned ba) {
-    asm volatile("ds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %4 offset:%7\n\t"
-                 "ds_read_b128 %2, %5 offset:%6\n\tds_read_b128 %3, %5 offset:%7"
-                 : "=&v"(g0), "=&v"(g1), "=&v"(b0), "=&v"(b1)
-                 : "v"(ga), "v"(ba), "n"(IMM), "n"(IMM + 32));
-}
-template <int NEWER>
-__device__ __forceinline__ void lnw_vec_wait(u32x4& g0, u32x4& g1, u32x4& b0, u32x4& b1) {
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(g0), "+v"(g1), "+v"(b0), "+v"(b1) : "n"(NEWER));
-}
-// gamma / beta of a slice (eight features: two 16-byte pieces of each vector) come through two register sets filled by
-// hand-issued LDS reads, one slice ahead: left to the compiler, the reads of all slices are hoisted to the top (128
-// registers at latent 128: spills), or each slice waits out its own LDS round trip.  The caller must have no other LDS
-// reads in flight that it still counts on (lgkmcnt is shared).
+// gamma / beta of a slice (eight features: two 16-byte pieces of each vector) are read one slice ahead (plain LDS loads:
+// hand-issued asm reads with early-clobber register quads cost this kernel 60-110 spilled registers); the scheduling
+// barrier per slice keeps the compiler from hoisting every slice's reads to the top (128 registers at latent 128).
 template <bool RES, int DT, int K0, int K1>
 __device__ __forceinline__ void ln_affine_w(const f32x16 (&acc)[DT], f32x16 (&ev)[DT], bf16x8 (&in)[2 * DT], unsigned lnv, int h,
                                             LnStats st) {
     if constexpr (K1 > K0) {
         constexpr int D = 32 * DT;
-#if CGNN_W8_LN_ASM == 2
-        const unsigned ga = lnv + 16u * (unsigned)h, ba = ga + (unsigned)D * 4u;
-        u32x4 vg[2][2], vb[2][2];
-        lnw_vec_read<(32 * (K0 >> 1) + 16 * (K0 & 1)) * 4>(vg[K0 & 1][0], vg[K0 & 1][1], vb[K0 & 1][0], vb[K0 & 1][1], ga, ba);
-#elif CGNN_W8_LN_ASM == 1
-        const unsigned ga = lnv + 16u * (unsigned)h, ba = ga + (unsigned)D * 4u;
-        u32x4 vg[1][2], vb[1][2];
-#else
-        const LdsVecPtr gp = (LdsVecPtr)(uintptr_t)lnv;
+        const LdsVecPtr gp = (LdsVecPtr)(uintptr_t)lnv + 4 * h;
+        f32x4 gm[2][2], bt[2][2];
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+            gm[K0 & 1][gg] = *(LdsVec4Ptr)(gp + 32 * (K0 >> 1) + 8 * (2 * (K0 & 1) + gg));
+            bt[K0 & 1][gg] = *(LdsVec4Ptr)(gp + D + 32 * (K0 >> 1) + 8 * (2 * (K0 & 1) + gg));
+        }
         __builtin_amdgcn_sched_barrier(0);
-#endif
         static_for_each([&](auto kc) __attribute__((always_inline)) {
-            constexpr int k = decltype(kc)::value + K0, t = k >> 1, s = k & 1;
-#if CGNN_W8_LN_ASM == 2
-            constexpr int cur = k & 1, nxt = cur ^ 1;
+            constexpr int k = decltype(kc)::value + K0, t = k >> 1, s = k & 1, cur = k & 1, nxt = cur ^ 1;
             if constexpr (k + 1 < K1) {
                 constexpr int t1 = (k + 1) >> 1, s1 = (k + 1) & 1;
-                lnw_vec_read<(32 * t1 + 16 * s1) * 4>(vg[nxt][0], vg[nxt][1], vb[nxt][0], vb[nxt][1], ga, ba);
-                lnw_vec_wait<4>(vg[cur][0], vg[cur][1], vb[cur][0], vb[cur][1]);
-            } else {
-                lnw_vec_wait<0>(vg[cur][0], vg[cur][1], vb[cur][0], vb[cur][1]);
+#pragma unroll
+                for (int gg = 0; gg < 2; ++gg) {
+                    gm[nxt][gg] = *(LdsVec4Ptr)(gp + 32 * t1 + 8 * (2 * s1 + gg));
+                    bt[nxt][gg] = *(LdsVec4Ptr)(gp + D + 32 * t1 + 8 * (2 * s1 + gg));
+                }
             }
-#elif CGNN_W8_LN_ASM == 1
-            constexpr int cur = 0;
-            lnw_vec_read<(32 * t + 16 * s) * 4>(vg[0][0], vg[0][1], vb[0][0], vb[0][1], ga, ba);
-            lnw_vec_wait<0>(vg[0][0], vg[0][1], vb[0][0], vb[0][1]);
-#endif
 #ifdef CGNN_W8_ABL_LN       // (developer timing build, wrong results: keeps the MFMAs alive)
             packw_slice<false, DT, t, s>(in, acc);
 #pragma unroll
@@ -318,19 +300,12 @@ __device__ __forceinline__ void ln_affine_w(const f32x16 (&acc)[DT], f32x16 (&ev
 #pragma unroll
             for (int gg = 0; gg < 2; ++gg) {
                 const int g = 2 * s + gg;
-#if CGNN_W8_LN_ASM
-                const f32x4 gm = __builtin_bit_cast(f32x4, vg[cur][gg]);
-                const f32x4 bt = __builtin_bit_cast(f32x4, vb[cur][gg]);
-#else
-                const f32x4 gm = *(LdsVec4Ptr)(gp + 32 * t + 8 * g + 4 * h);
-                const f32x4 bt = *(LdsVec4Ptr)(gp + D + 32 * t + 8 * g + 4 * h);
-#endif
                 float e[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float nrm = __builtin_fmaf(acc[t][4 * g + c], st.rstd, st.nmr);
-                    const float base = RES ? bt[c] + ev[t][4 * g + c] : bt[c];
-                    e[c] = __builtin_fmaf(nrm, gm[c], base);
+                    const float base = RES ? bt[cur][gg][c] + ev[t][4 * g + c] : bt[cur][gg][c];
+                    e[c] = __builtin_fmaf(nrm, gm[cur][gg][c], base);
                     ev[t][4 * g + c] = e[c];
                 }
                 v[2 * gg] = pack_bf16(e[0], e[1]);
@@ -468,8 +443,8 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
 
     // A tile's per-lane inputs: the sender rows' byte offsets for the staging gathers, the receiver chunk's offset and (ENC)
     // the lane's eight edge features (k-step 0 of the encoder's operand: element j = feature 8 (j >> 2) + 4 h + (j & 3)).
-    // Loaded a whole interval ahead for the next tile (in the last block of the current one): their latency is a trip to
-    // HBM, and every wave of the workgroup would otherwise sit in it at the same time.
+    // Loaded a whole tile ahead (at the top of the current tile, seven registers): their latency is a trip to HBM, and every
+    // wave of the workgroup would otherwise sit in it at the same time.
     struct TileIn {      // raw loaded values: nothing is computed from them before the tile starts (a use would wait for the load)
         int src_lo, src_hi, dst_row;
         f32x4 q;          // ENC: the edge's (<= 4) features: one aligned 16-byte load (the launcher checks enc_in <= 4, ld_attr % 4 == 0)
@@ -499,12 +474,14 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
         {
             so_lo = (unsigned)nxt.src_lo * (unsigned)D * 2u;
             so_hi = (unsigned)nxt.src_hi * (unsigned)D * 2u;
+            const f32x4 q_now = nxt.q;
+            load_tile_in(tile_next, nxt);
             if (ENC) {
                 // lane (r, h), k-step 0, element j = edge feature 8 (j >> 2) + 4 h + (j & 3): features 0 .. 3 sit in the h = 0 lanes
                 const int fin = a.enc_in_dim;
                 float v[8];
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) v[jj] = (jj < 4 && h == 0 && jj < fin) ? nxt.q[jj] : 0.f;
+                for (int jj = 0; jj < 8; ++jj) v[jj] = (jj < 4 && h == 0 && jj < fin) ? q_now[jj] : 0.f;
                 u32x4 w;
                 w[0] = pack_bf16(v[0], v[1]);
                 w[1] = pack_bf16(v[2], v[3]);
@@ -562,13 +539,15 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
                     static_for_each([&](auto ic) __attribute__((always_inline)) { stage_ps(CGNN_IC(1), ic, tps); },
                                     std::make_integer_sequence<int, 4>{});
                 }
+                // (measured and dropped: the selector MFMAs of a row tile right behind its two LayerNorm slices, so that they
+                // run under the next slices' vector work: no gain, four spilled registers)
                 ln_affine_w<PEND == 2, DT, KA, 2 * DT>(acc, ev, inb[0], ring.lnbuf(lnpar ^ 1), h, lnst);
                 if constexpr (!IS_ENC) read_pd();
             }
             const unsigned base = ring.base();
             CGNN_W8_STAMP(9);
             if constexpr (IS_ENC) {
-                bias_rowsw<DT>(acc, ring.vec_addr(), h);
+                bias_rowsw<DT, 0, DT>(acc, ring.vec_addr() + (unsigned)D * 4u, h);      // the encoder's first bias: vector 1 of its own chunk
             } else if constexpr (PEND != 0) {
                 selp_rows<DT, 0, DT / 2>(acc, ps, pd, sel0, sel1);
                 CGNN_S32_VMCNT(0);      // the second half of the sender rows (requested a LayerNorm ago; nothing newer in flight)
@@ -579,14 +558,21 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
             }
             CGNN_W8_STAMP(10);
             const bf16x8 (&in0)[KS0] = reinterpret_cast<const bf16x8(&)[KS0]>(inb[0][0]);
+            // each finished row tile is packed under the next one's MFMAs, and its accumulators take the NEXT layer's bias
+            // (vector 0 of this chunk: the image stores every bias one chunk early, so that these reads are over before the
+            // barrier instead of opening the next step with an LDS round trip)
             wblockw<DT, KS0>(acc, in0, base, make_fill([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value, t = q / KS0 - 1, w = q % KS0;
                 pieces_first(qc);
                 if constexpr (t >= 0 && w == (KS0 > 2 ? 1 : KS0 - 1)) packw_slice<true, DT, (t < 0 ? 0 : t), 0>(inb[1], acc);
-                if constexpr (t >= 0 && w == (KS0 > 4 ? 3 : KS0 - 1)) packw_slice<true, DT, (t < 0 ? 0 : t), 1>(inb[1], acc);
+                if constexpr (t >= 0 && w == (KS0 > 4 ? 3 : KS0 - 1)) {
+                    packw_slice<true, DT, (t < 0 ? 0 : t), 1>(inb[1], acc);
+                    bias_rowsw<DT, (t < 0 ? 0 : t), (t < 0 ? 0 : t) + 1>(acc, ring.vec_addr(), h);
+                }
             }));
             packw_slice<true, DT, DT - 1, 0>(inb[1], acc);
             packw_slice<true, DT, DT - 1, 1>(inb[1], acc);
+            bias_rowsw<DT, DT - 1, DT>(acc, ring.vec_addr(), h);
             ring.dma_done();
             ring.template interval_end<0, 11>();
             ring.advance();
@@ -595,15 +581,18 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
         auto step_hidden = [&](auto lc) __attribute__((always_inline)) {
             constexpr int l = decltype(lc)::value;
             CGNN_W8_STAMP(14);
-            bias_rowsw<DT>(acc, ring.vec_addr(), h);
             wblockw<DT, KS>(acc, inb[l & 1], ring.base(), make_fill([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value, t = q / KS - 1, w = q % KS;
                 pieces_first(qc);
                 if constexpr (t >= 0 && w == (KS > 2 ? 1 : KS - 1)) packw_slice<true, DT, (t < 0 ? 0 : t), 0>(inb[(l + 1) & 1], acc);
-                if constexpr (t >= 0 && w == (KS > 4 ? 3 : KS - 1)) packw_slice<true, DT, (t < 0 ? 0 : t), 1>(inb[(l + 1) & 1], acc);
+                if constexpr (t >= 0 && w == (KS > 4 ? 3 : KS - 1)) {
+                    packw_slice<true, DT, (t < 0 ? 0 : t), 1>(inb[(l + 1) & 1], acc);
+                    bias_rowsw<DT, (t < 0 ? 0 : t), (t < 0 ? 0 : t) + 1>(acc, ring.vec_addr(), h);
+                }
             }));
             packw_slice<true, DT, DT - 1, 0>(inb[(l + 1) & 1], acc);
             packw_slice<true, DT, DT - 1, 1>(inb[(l + 1) & 1], acc);
+            bias_rowsw<DT, DT - 1, DT>(acc, ring.vec_addr(), h);
             ring.dma_done();
             ring.template interval_end<0, 15>();
             ring.advance();
@@ -612,19 +601,24 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
         auto step_last = [&](auto p_tag, auto res_tag, const __bf16* nps, const __bf16* npd) __attribute__((always_inline)) {
             constexpr bool WITH_P = decltype(p_tag)::value, RES = decltype(res_tag)::value;
             CGNN_W8_STAMP(0);
-            bias_rowsw<DT>(acc, ring.vec_addr(), h);
             CGNN_W8_STAMP(1);
+            LnSums sums;
+            ln_sums_clear(sums);
             wblockw<DT, KS>(acc, inb[NH & 1], ring.base(), make_fill([&](auto qc) __attribute__((always_inline)) {
-                constexpr int q = decltype(qc)::value;
+                constexpr int q = decltype(qc)::value, t = q / KS - 1, w = q % KS;
                 pieces_first(qc);
                 if constexpr (WITH_P && q >= NP && q < NP + 4) stage_ps(CGNN_IC(0), CGNN_IC(q - NP), nps);
                 if constexpr (WITH_P && q == NP + 4) pdchunk = load_pd_chunk(npd, dchunk);
-                if constexpr (!WITH_P && q == NP) load_tile_in(tile_next, nxt);      // the tile's last block: the next tile's inputs
+                // LayerNorm's sums of a finished row tile, under the next row tile's MFMAs
+                if constexpr (t >= 0 && w == (KS > 2 ? 2 : KS - 1)) ln_sums_add<DT, (t < 0 ? 0 : t), 0>(sums, acc);
+                if constexpr (t >= 0 && w == (KS > 4 ? 4 : KS - 1)) ln_sums_add<DT, (t < 0 ? 0 : t), 1>(sums, acc);
             }));
             CGNN_W8_STAMP(2);
             // LayerNorm: the statistics and the first KA affine slices here (vectors straight from this chunk), the rest behind
-            // the barrier: with LAG 1 this balances the vector work of the two intervals a pass boundary touches
-            lnst = ln_stats_w<DT>(acc);
+            // the barrier
+            ln_sums_add<DT, DT - 1, 0>(sums, acc);
+            ln_sums_add<DT, DT - 1, 1>(sums, acc);
+            lnst = ln_stats_finish<DT>(sums);
             ln_affine_w<RES, DT, 0, KA>(acc, ev, inb[0], ring.vec_addr() + (unsigned)D * 4u, h, lnst);
             // the LayerNorm vectors of this chunk, for the affine part that runs in the next interval (when this slot may
             // already be refilled): waves 0-3 copy gamma | beta (2 D floats) aside
@@ -638,7 +632,7 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
             }
             lnpar ^= 1;
             ring.dma_done();
-            ring.template interval_end<(WITH_P ? 5 : 4), 3>();      // (the next tile's inputs: at least four loads)
+            ring.template interval_end<(WITH_P ? 5 : 0), 3>();
             ring.advance();
         };
         auto hidden_steps = [&]() __attribute__((always_inline)) {
@@ -739,6 +733,27 @@ static int launch_w8(const S32Args& a, const __bf16* ps, const __bf16* pd, int64
 }  // namespace cgnn
 
 using namespace cgnn;
+
+// The image of cgnn_edge_stream_image_build with every bias moved ONE CHUNK EARLY: vector 0 of chunk c = the bias of chunk
+// c + 1's layer (zeros where that layer has none: a round's first Linear, whose bias lives in its Pd table), and vector 1
+// of chunk 0 = that chunk's own bias (the encoder's first Linear; first-layer chunks carry no LayerNorm vectors there).
+extern "C" int cgnn_edge_stream_image_build_w8(const cgnn_mlp* rounds, int32_t num_rounds, const cgnn_mlp* encoder,
+                                               int32_t latent, void* image, size_t image_bytes, void* stream) {
+    int rc = cgnn_edge_stream_image_build(rounds, num_rounds, encoder, latent, image, image_bytes, stream);
+    if (rc != CGNN_OK) return rc;
+    const size_t stride = s32_stride(latent);
+    const int nh = rounds[0].num_hidden_layers;
+    const int count = (num_rounds + (encoder ? 1 : 0)) * (nh + 1);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t vbytes = (size_t)latent * 4, voff = (size_t)latent * latent * 2;
+    char* img = (char*)image;
+    rc = check_hip(hipMemcpyAsync(img + voff + vbytes, img + voff, vbytes, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(own bias)");
+    for (int c = 0; c + 1 < count && rc == CGNN_OK; ++c)
+        rc = check_hip(hipMemcpyAsync(img + (size_t)c * stride + voff, img + (size_t)(c + 1) * stride + voff, vbytes,
+                                      hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(bias, one chunk early)");
+    if (rc == CGNN_OK) rc = check_hip(hipMemsetAsync(img + (size_t)(count - 1) * stride + voff, 0, vbytes, st), "hipMemsetAsync(last bias)");
+    return rc;
+}
 
 extern "C" int cgnn_edge_stream_w8_supported(int32_t latent, int32_t num_hidden_layers, int32_t fixed_k) {
     const bool k_ok = fixed_k >= 8 && (fixed_k <= 32 ? 32 % fixed_k == 0 : fixed_k % 32 == 0);

@@ -412,8 +412,10 @@ class ShardedForward:
             sh = self.sh
             enc = self.P["enc_edge"] if self._enc_in_stream else None
             if self.image is not None:
-                self.el = ops.edge_stream_run(self.image, self.ps, self.pd, sh.src_local, sh.dst_local, self.el, self.el,
-                                              sh.edge_attr if self._enc_in_stream else None)
+                attr = sh.edge_attr if self._enc_in_stream else None
+                image, kernel = self.model._edge_stream_plan(self.P, sh.k, sh.src_local.numel(), attr)
+                self.el = ops.edge_stream_run(image, self.ps, self.pd, sh.src_local, sh.dst_local, self.el, self.el, attr,
+                                              kernel=kernel, lag=int(getattr(self.model, "edge_stream_lag", 0)), fixed_k=sh.k)
             else:
                 self.el = ops.edge_stream([p.edge for p in self.P["rounds"]], self.ps, self.pd, sh.src_local,
                                           sh.dst_local, self.el, self.el, enc, sh.edge_attr if enc is not None else None)

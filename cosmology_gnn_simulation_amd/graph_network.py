@@ -309,7 +309,7 @@ def _run_round(p: _PackedProcessor, x: torch.Tensor, e: torch.Tensor, src, dst, 
 
 def _run_rounds_fused(rounds, x: torch.Tensor, e, src, dst, fixed_k: int, agg: Optional[torch.Tensor],
                       encoder=None, edge_attr: Optional[torch.Tensor] = None, image=None, keep: Optional[dict] = None,
-                      stream_kernel: str = "tile32", stream_lag: int = 1):
+                      stream_kernel: str = "tile32", stream_lag: int = 0):
     """All residual rounds under the reference's data flow (aggregation of sender NODE latents): the node
     stream does not read the edge stream, so it runs first and leaves every round's Ps / Pd tables behind (the node
     kernel's epilogue writes round i+1's); then one launch applies all edge updates while each edge tile stays in
@@ -425,8 +425,8 @@ class EncodeProcessDecode(nn.Module):
         # which one-launch kernel: "tile32" = cgnn_edge_stream_run (32-edge MFMA tiles, one wave per SIMD, two tiles per
         # wave), "tile32w" = cgnn_edge_stream_run_w8 (32-edge tiles, two waves per SIMD, one tile each; latent 128 only,
         # other shapes take "tile32"), "tile16" = cgnn_edge_stream (16-edge tiles; the first generation, kept for comparison)
-        self.edge_stream_kernel = "tile32"
-        self.edge_stream_lag = 1      # "tile32w": second wave of a SIMD one layer behind the first (0: in step)
+        self.edge_stream_kernel = "tile32w"
+        self.edge_stream_lag = 0      # "tile32w": second wave of a SIMD one layer behind the first (1) or in step (0)
         # tests only: forward_with_latents() also returns the one-launch edge stream's inputs (every round's Ps / Pd table,
         # the renumbered edge list and edge features) under "stream_inputs", so that sampled edge rows can be recomputed
         self.keep_stream_inputs = False
@@ -471,9 +471,27 @@ class EncodeProcessDecode(nn.Module):
             dec_acc=_pack_mlp(self.decoder_acc, self.node_precision),
             dec_tr=_pack_mlp(self.decoder_temp_rate, self.node_precision),
             image=ops.StreamImage([p.edge for p in rounds], enc_edge if enc_in_image else None) if tile32 else None,
+            image_w8=None,      # the same for cgnn_edge_stream_run_w8 (every bias one chunk early), built on first use
+            image_parts=([p.edge for p in rounds], enc_edge if enc_in_image else None) if tile32 else None,
         )
         self._packed = (key, packed)
         return packed
+
+    def _edge_stream_plan(self, P, fixed_k: int, num_edges: int, edge_attr: Optional[torch.Tensor]):
+        """-> (image, kernel) for ``ops.edge_stream_run``: the two-waves-per-SIMD kernel (``cgnn_edge_stream_run_w8``, its own
+        image, built on first use) where ``edge_stream_kernel == "tile32w"`` and the shape, the graph layout (receiver-sorted,
+        fixed in-degree 8, 16, 32, ...) and the edge-feature layout qualify; otherwise ``cgnn_edge_stream_run``."""
+        image = P["image"]
+        if image is None or self.edge_stream_kernel != "tile32w":
+            return image, "tile32"
+        ok = ops.stream_w8_supported(image.latent, image.nh, fixed_k) and num_edges % max(fixed_k, 1) == 0
+        if ok and image.enc_in:
+            ok = image.enc_in <= 4 and edge_attr is not None and edge_attr.stride(0) % 4 == 0 and edge_attr.data_ptr() % 16 == 0
+        if not ok:
+            return image, "tile32"
+        if P["image_w8"] is None:
+            P["image_w8"] = ops.StreamImage(*P["image_parts"], kernel="tile32w")
+        return P["image_w8"], "tile32w"
 
     def _can_fuse_rounds(self, rounds, latent: int) -> bool:
         """One launch for the whole edge stream (``cgnn_edge_stream``): only under the reference's own data flow
@@ -610,11 +628,10 @@ class EncodeProcessDecode(nn.Module):
             rounds = P["rounds"]
             keep = {} if (want_latents and getattr(self, "keep_stream_inputs", False)) else None
             if fuse:
-                w8 = (image is not None and self.edge_stream_kernel == "tile32w" and
-                      ops.stream_w8_supported(image.latent, image.nh, fixed_k) and src.numel() % max(fixed_k, 1) == 0)
+                image, stream_kernel = self._edge_stream_plan(P, fixed_k, src.numel(), edge_attr)
                 xl, el = _run_rounds_fused(rounds, xl, el, src, dst, fixed_k, agg,
                                            P["enc_edge"] if enc_in_stream else None, edge_attr, image, keep,
-                                           "tile32w" if w8 else "tile32", int(getattr(self, "edge_stream_lag", 1)))
+                                           stream_kernel, int(getattr(self, "edge_stream_lag", 0)))
                 rounds = []
             for i, p in enumerate(rounds):
                 # residual streams updated in place (reference graph_network.py:181-182); the node kernel also

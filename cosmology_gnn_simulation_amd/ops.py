@@ -351,8 +351,13 @@ class StreamImage:
             return False
         return _lib.load().cgnn_edge_stream_image_bytes(latent, nh, rounds, 1 if enc_in is not None else 0) > 0
 
-    def __init__(self, mlps: Sequence[PackedMLP], encoder: Optional[PackedMLP] = None):
+    def __init__(self, mlps: Sequence[PackedMLP], encoder: Optional[PackedMLP] = None, kernel: str = "tile32"):
+        """``kernel``: which kernel the image is for -- ``"tile32w"`` (``cgnn_edge_stream_run_w8``) wants every bias one chunk
+        early (``cgnn_edge_stream_image_build_w8``); the images are not interchangeable."""
         lib = _lib.load()
+        if kernel not in ("tile32", "tile32w"):
+            raise CgnnError(f"StreamImage: unknown kernel {kernel!r}")
+        self.kernel = kernel
         self.rounds = len(mlps)
         self.latent = mlps[0].out_dim
         self.nh = mlps[0].num_hidden_layers
@@ -366,8 +371,9 @@ class StreamImage:
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         arr = (Mlp * self.rounds)(*[m.struct() for m in mlps])
         enc = encoder.struct() if encoder is not None else None
-        check(lib.cgnn_edge_stream_image_build(arr, self.rounds, C.byref(enc) if enc is not None else None, self.latent,
-                                               self.buf.data_ptr(), nbytes, stream_ptr(dev)), "cgnn_edge_stream_image_build")
+        build = lib.cgnn_edge_stream_image_build_w8 if kernel == "tile32w" else lib.cgnn_edge_stream_image_build
+        check(build(arr, self.rounds, C.byref(enc) if enc is not None else None, self.latent, self.buf.data_ptr(), nbytes,
+                    stream_ptr(dev)), "cgnn_edge_stream_image_build")
         self._keep = (list(mlps), encoder)     # the copies are asynchronous: keep the sources alive
 
 
@@ -389,6 +395,8 @@ def edge_stream_run(image: StreamImage, ps_all: torch.Tensor, pd_all: torch.Tens
     ``stream_w8_supported``)."""
     if kernel not in ("tile32", "tile32w"):
         raise CgnnError(f"edge_stream_run: unknown kernel {kernel!r}")
+    if image.kernel != kernel:
+        raise CgnnError(f"edge_stream_run: the image was built for {image.kernel!r}, not {kernel!r} (StreamImage(..., kernel=...))")
     src, dst = i32c(src, "src"), i32c(dst, "dst")
     ne, latent = src.numel(), image.latent
     if image.enc_in:

@@ -264,8 +264,12 @@ int cgnn_edge_stream_run(const void* image, size_t image_bytes, int32_t latent, 
  * as for cgnn_aggregate), fixed_k in {8, 16, 32, 64, 96, ...}, latent == hidden == 128, 1..3 hidden layers
  * (cgnn_edge_stream_w8_supported); every other shape or edge list: cgnn_edge_stream_run.
  * lag = 1: the second wave of every SIMD runs one layer behind the first (their LayerNorms never coincide), 0: in step;
- * results do not depend on lag. */
+ * results do not depend on lag.
+ * Its image differs from cgnn_edge_stream_run's in one thing: every bias sits one chunk early (the kernel reads a layer's
+ * bias while the previous layer still computes); cgnn_edge_stream_image_build_w8 builds it (same arguments and size). */
 int cgnn_edge_stream_w8_supported(int32_t latent, int32_t num_hidden_layers, int32_t fixed_k);
+int cgnn_edge_stream_image_build_w8(const cgnn_mlp* rounds, int32_t num_rounds, const cgnn_mlp* encoder, int32_t latent,
+                                    void* image, size_t image_bytes, void* stream);
 int cgnn_edge_stream_run_w8(const void* image, size_t image_bytes, int32_t latent, int32_t num_hidden_layers,
                             int32_t num_rounds, int32_t enc_in_dim, const void* ps_all, const void* pd_all,
                             int64_t round_stride, const int32_t* src, const int32_t* dst, int64_t num_edges,

@@ -37,7 +37,8 @@ m.load_state_dict(synthetic.make_state_dict(d, d, 2, L, 3))
 m = m.to(dev).eval()
 m.edge_precision, m.node_precision = "bf16", "fp16x2"
 P = m._pack(17, 4)
-image = P["image"] if not a.no_encoder else ops.StreamImage([r.edge for r in P["rounds"]], None)
+parts = ([r.edge for r in P["rounds"]], None if a.no_encoder else P["enc_edge"])
+images = {k: ops.StreamImage(*parts, kernel=k) for k in ("tile32", "tile32w")}
 E = n * k
 ps_all = torch.randn(L, n, d, device=dev).to(torch.bfloat16)
 pd_all = torch.randn(L, n, d, device=dev).to(torch.bfloat16)
@@ -52,9 +53,9 @@ for v in a.variants.split(","):
 
 def run(kern, lag):
     if a.no_encoder:
-        ops.edge_stream_run(image, ps_all, pd_all, src, dst, e, e, None, kernel=kern, lag=lag, fixed_k=fk if a.fixed_k else 0)
+        ops.edge_stream_run(images[kern], ps_all, pd_all, src, dst, e, e, None, kernel=kern, lag=lag, fixed_k=fk if a.fixed_k else 0)
     else:
-        ops.edge_stream_run(image, ps_all, pd_all, src, dst, None, e, ea, kernel=kern, lag=lag, fixed_k=fk if a.fixed_k else 0)
+        ops.edge_stream_run(images[kern], ps_all, pd_all, src, dst, None, e, ea, kernel=kern, lag=lag, fixed_k=fk if a.fixed_k else 0)
 
 
 times = {v[0]: [] for v in variants}

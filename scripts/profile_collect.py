@@ -53,7 +53,7 @@ def pick(name, needle):
 
 
 entries = {}
-for key, name, needle, src in (("edge_stream+enc:1000000:16:128:10", "edge_stream", "edge_stream32", "edge_stream32.hip"),
+for key, name, needle, src in (("edge_stream+enc:1000000:16:128:10", "edge_stream", "edge_stream32w", "edge_stream32w.hip"),
                                ("node_block:1000000:128", "node_block", "f2ring", "node_block_f2.hip"),
                                ("aggregate:1000000:16:128", "aggregate_planned", "aggregate_planned", "aggregate_plan.hip"),
                                ("aggregate_plain:1000000:16:128", "aggregate", "aggregate_fixedk", "runtime.hip"),

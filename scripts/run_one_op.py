@@ -56,10 +56,13 @@ if a.op == "edge_stream":
     mL.load_state_dict(synthetic.make_state_dict(d, d, 2, L, 3))
     mL = mL.to(dev).eval()
     mL.edge_precision, mL.node_precision = a.edge_precision, a.node_precision
-    mL.edge_stream_kernel = os.environ.get("CGNN_RUN_STREAM_KERNEL", "tile32")
+    mL.edge_stream_kernel = os.environ.get("CGNN_RUN_STREAM_KERNEL", "tile32w")
     PL = mL._pack(17, 4)
     roundsL = [r.edge for r in PL["rounds"]]
     imageL = PL["image"]
+    kernL = "tile32"
+    if imageL is not None:
+        imageL, kernL = mL._edge_stream_plan(PL, fk, n * k, ea)
     encL = None if imageL is not None else (PL["enc_edge"] if mL._encoder_fits_stream(PL) else None)
     ps_all = torch.randn(L, n, d, device=dev, generator=gen).to(torch.bfloat16)
     pd_all = torch.randn(L, n, d, device=dev, generator=gen).to(torch.bfloat16)
@@ -81,7 +84,8 @@ fn = {
     "node_block_proj": lambda: ops.node_block(r0.node, r0.wx, r0.wa, x, agg, x, True,
                                               (r1.ws_fused, r1.wd_fused, ps2, pd2, r1.p_format)),
     "edge_stream": lambda: (ops.edge_stream_run(imageL, ps_all, pd_all, src, dst, None if imageL.enc_in else e, e,
-                                                ea if imageL.enc_in else None) if imageL is not None else
+                                                ea if imageL.enc_in else None, kernel=kernL, lag=mL.edge_stream_lag,
+                                                fixed_k=fk) if imageL is not None else
                             ops.edge_stream(roundsL, ps_all, pd_all, src, dst, None if encL else e, e, encL,
                                             ea if encL else None)),
     "edge_block": lambda: ops.edge_block(p.edge, ps, pd, src, dst, e, e, None, True),

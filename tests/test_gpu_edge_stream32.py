@@ -100,7 +100,7 @@ def _fixed_k(prob, n, k):
 def _run(src, dst, ps, pd, mlps, enc, attr, e0, kernel=("tile32", 0), fixed_k=0):
     packed = [ops.PackedMLP([(lin[0][0], None)] + lin[1:], ln, "bf16") for lin, ln in mlps]
     penc = ops.PackedMLP(enc[0], enc[1], "bf16") if enc is not None else None
-    image = ops.StreamImage(packed, penc)
+    image = ops.StreamImage(packed, penc, kernel=kernel[0])
     e_in = None if enc is not None else ops.TiledRows.from_rows(e0)
     out = ops.edge_stream_run(image, _s32_table(ps), _s32_table(pd), src, dst, e_in, None, attr if enc is not None else None,
                               kernel=kernel[0], lag=kernel[1], fixed_k=fixed_k)
@@ -158,7 +158,7 @@ def test_edge_stream_run_is_deterministic_and_in_place(kernel):
     assert torch.equal(a, b)
     src, dst, ps, pd, mlps, enc, attr, e0 = prob
     packed = [ops.PackedMLP([(lin[0][0], None)] + lin[1:], ln, "bf16") for lin, ln in mlps]
-    image = ops.StreamImage(packed, None)
+    image = ops.StreamImage(packed, None, kernel=kernel[0])
     e = ops.TiledRows.from_rows(e0)
     ops.edge_stream_run(image, _s32_table(ps), _s32_table(pd), src, dst, e, e, kernel=kernel[0], lag=kernel[1], fixed_k=fk)   # e_out aliases e_in
     assert torch.equal(e.to_rows(), a)

@@ -537,9 +537,11 @@ def _same_edge_stream(a, b, kernel, ctx=None):
         assert torch.equal(a["edge_latent"], b["edge_latent"]), ctx
     else:
         assert rel_l2(a["edge_latent"], b["edge_latent"]) <= 1e-2, ctx
+        import edge_checks as ec
+        ec.assert_rows_close(a["edge_latent"], b["edge_latent"], 5e-2, f"one-launch vs per-round edge latents {ctx}")
 
 
-@pytest.mark.parametrize("kernel", ["tile32", "tile16"])
+@pytest.mark.parametrize("kernel", ["tile32w", "tile32", "tile16"])
 @pytest.mark.parametrize("n,k,latent,nh,steps", [(5000, 16, 128, 2, 3), (300, 8, 128, 2, 10), (3000, 16, 64, 1, 2),
                                                  (2600, 16, 32, 3, 1), (40000, 16, 128, 2, 2), (777, 8, 64, 2, 5)])
 def test_all_rounds_in_one_launch_is_bitwise_equivalent(n, k, latent, nh, steps, kernel):
@@ -571,7 +573,7 @@ def test_all_rounds_in_one_launch_is_bitwise_equivalent(n, k, latent, nh, steps,
     assert "edge_stream" not in tm.summary()
 
 
-@pytest.mark.parametrize("kernel", ["tile32", "tile16"])
+@pytest.mark.parametrize("kernel", ["tile32w", "tile32", "tile16"])
 @pytest.mark.parametrize("seed", range(12))
 def test_all_rounds_in_one_launch_random_shapes(seed, kernel):
     """Randomised shapes for the one-launch edge stream (tile counts below, at and above the grid's wave count, odd
