@@ -92,6 +92,8 @@ struct W8Geom {
 //          a few hundred).
 // Every wave issues NP pieces per chunk; where 8 NP exceeds the chunk's pieces the surplus ones repeat an earlier
 // piece (same bytes to the same place), which keeps every wave's operation count, and so every wait count, the same.
+// (Measured and dropped: skipping the surplus pieces with a wave-uniform branch -- control flow inside the MFMA blocks
+// cost 173 spilled registers and a 2.7 x slower kernel.)
 template <class W, int LAG>
 struct RingW {
     const char* image;

@@ -23,7 +23,7 @@ pmc() {   # name op args... -- then counter sets
   done
 }
 TRAFFIC=("FETCH_SIZE" "WRITE_SIZE")
-SQ=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM SQ_WAVES")
+SQ=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM SQ_WAVES" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT")
 echo "== edge stream (+ encoder)"
 pmc edge_stream edge_stream --real-graph --edge-precision bf16 --node-precision fp16x2 -- "${TRAFFIC[@]}" "${SQ[@]}"
 echo "== node block (fp16x2, projections fused)"
