@@ -7,6 +7,7 @@ non-zero status.  Outputs are torch tensors so callers keep normal ownership.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -433,8 +434,10 @@ def edge_stream_run(image: StreamImage, ps_all: torch.Tensor, pd_all: torch.Tens
 class AggregatePlan:
     """Per-graph plan of the fixed-k aggregation (``cgnn_aggregate_plan_build``): per block of 64 receivers the distinct
     sender rows and each edge's position among them, so that a round stages every distinct row once in LDS instead of
-    gathering it once per edge.  Valid for the ``gather`` tensor it was built from (kept alive here), in its version at
-    build time."""
+    gathering it once per edge.  Valid for the ``gather`` tensor it was built from, in its version at build time.  The plan
+    holds only a WEAK reference to that tensor (``AggregatePlan.of`` caches the plan ON the tensor: a strong reference back
+    would make a cycle, and a dropped graph's sender list and plan -- 130 MB at 1 M x 16 -- would wait for the cyclic
+    collector instead of being freed with the graph); ``aggregate`` is handed the live tensor."""
 
     MIN_NODES = 8192      # below this the plain gather is launch-bound either way
 
@@ -445,7 +448,9 @@ class AggregatePlan:
         nbytes = _lib.load().cgnn_aggregate_plan_bytes(num_nodes, fixed_k)
         if nbytes == 0:
             raise CgnnError(f"AggregatePlan: fixed_k={fixed_k} cannot be planned")
-        self.gather, self.num_nodes, self.fixed_k = gather, num_nodes, fixed_k
+        self._gather_ref = weakref.ref(gather)
+        self.gather_ptr, self.device = gather.data_ptr(), gather.device
+        self.num_nodes, self.fixed_k = num_nodes, fixed_k
         self.version = gather._version
         self.blob = torch.empty(nbytes, dtype=torch.uint8, device=gather.device)
         with _timed("aggregate_plan", gather.device):
@@ -476,17 +481,17 @@ def aggregate(table, gather: Optional[torch.Tensor], dst: Optional[torch.Tensor]
     ``gather``): the planned fixed-k kernel, bit-identical results."""
     if plan is not None:
         table = f32c(table, "table")
-        if plan.gather is not gather and (gather is None or plan.gather.data_ptr() != gather.data_ptr()):
+        if gather is None or gather.data_ptr() != plan.gather_ptr or gather.dtype != torch.int32:
             raise CgnnError("aggregate: the plan was built for another sender list")
-        if plan.version != plan.gather._version:
+        if plan.version != gather._version:
             raise CgnnError("aggregate: the sender list changed after the plan was built")
         if fixed_k != plan.fixed_k or num_nodes != plan.num_nodes or table.shape[1] % 32:
             raise CgnnError("aggregate: the plan does not match this call")
         if out is None:
             out = torch.empty((num_nodes, table.shape[1]), dtype=torch.float32, device=table.device)
-        _same_device(table, plan.gather, plan.blob, out)
+        _same_device(table, gather, plan.blob, out)
         with _timed("aggregate", table.device):
-            check(_lib.load().cgnn_aggregate_planned(table.data_ptr(), plan.gather.data_ptr(), plan.blob.data_ptr(),
+            check(_lib.load().cgnn_aggregate_planned(table.data_ptr(), gather.data_ptr(), plan.blob.data_ptr(),
                                                      num_nodes, fixed_k, table.shape[1], out.data_ptr(),
                                                      stream_ptr(table.device)), "cgnn_aggregate_planned")
         return out

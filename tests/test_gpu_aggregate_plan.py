@@ -72,6 +72,26 @@ def test_plan_is_bound_to_its_sender_list():
     assert ops.AggregatePlan.of(src, n, k, 36) is None
 
 
+def test_dropping_a_sender_list_frees_its_plan_without_the_cyclic_collector():
+    """AggregatePlan.of caches the plan on the sender tensor; the plan must not hold the tensor in return (a rollout builds a
+    new graph, sender list and 130-MB plan per step: a reference cycle would leave them to Python's cyclic collector)."""
+    import gc
+    n, k = 20000, 16
+    src = _knn_senders(n, k, 9)
+    gc.collect()
+    torch.cuda.synchronize()
+    gc.disable()
+    try:
+        base = torch.cuda.memory_allocated()
+        s2 = src.clone()
+        plan = ops.AggregatePlan.of(s2, n, k, 128)
+        assert plan is not None and torch.cuda.memory_allocated() >= base + plan.blob.numel()
+        del plan, s2
+        assert torch.cuda.memory_allocated() == base
+    finally:
+        gc.enable()
+
+
 def test_model_forward_is_unchanged_by_the_plan():
     """The whole forward with and without planned aggregation: bit-identical outputs."""
     from cosmology_gnn_simulation_amd import graph_network
