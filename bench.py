@@ -44,7 +44,7 @@ def parse_args():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--particles", type=int, default=None,
                    help="particles per GPU (--scaling weak) or in total (--scaling strong); default 1,000,000")
-    p.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+    p.add_argument("--scaling", default=None, choices=["weak", "strong"],
                    help="N > 1: weak = --particles per GPU (default), strong = --particles in total")
     p.add_argument("--config", default=None, choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"],
                    help="a BASELINE.json configuration: sets particles / neighbours / latent / rounds / precisions "
@@ -68,7 +68,7 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-particles", type=int, default=16384, help="bounded CPU-baseline sample size")
     p.add_argument("--cpu-threads", type=int, default=None, help="host threads for the CPU baseline (default: all)")
-    p.add_argument("--seed", type=int, default=None)   # 1234 + cfg index
+    p.add_argument("--seed", type=int, default=None)   # 1234 + configuration number
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="process-group backend for --gpus > 1 (gloo = single-GPU rehearsal, staged through the host)")
     p.add_argument("--hip-graph", action="store_true",
@@ -78,17 +78,15 @@ def parse_args():
     a = p.parse_args()
     # BASELINE.json configs[0..4] (N, k, latent, rounds, edge / node arithmetic, seed 1234 + cfg)
     presets = {"cfg1": (4096, 8, 64, 5, "fp32", "fp32", 1235, "weak"), "cfg2": (262144, 16, 128, 10, "fp16x2", "fp16x2", 1236, "weak"),
-               "cfg3": (1_000_000, 16, 128, 10, "bf16", "fp16x2", 1236, "weak"),
+               "cfg3": (1_000_000, 16, 128, 10, "bf16", "fp16x2", 1237, "weak"),
                "cfg4": (4_000_000, 16, 128, 10, "bf16", "fp16x2", 1238, "strong"),
                "cfg5": (1_000_000, 32, 256, 15, "bf16", "fp16x2", 1239, "strong")}
     pre = presets[a.config or "cfg3"]
     for name, val in zip(("particles", "neighbors", "latent", "mp_steps", "edge_precision", "node_precision", "seed"), pre):
         if getattr(a, name) is None:
             setattr(a, name, val)
-    if a.config in ("cfg4", "cfg5") and "--scaling" not in sys.argv:
-        a.scaling = pre[7]
-    if a.config == "cfg2" and "--seed" not in sys.argv:
-        a.seed = 1235 + 1
+    if a.scaling is None:
+        a.scaling = pre[7] if a.config in ("cfg4", "cfg5") else "weak"
     return a
 
 
@@ -154,6 +152,12 @@ def cpu_baseline(args, dev_outputs=None):
            "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(),
            "sample": f"oracle/cpu_ref.encode_process_decode, 1 forward, N={n} k={k} latent={d} L={L} fp32 "
                      f"({sec:.2f} s on {cores} host threads)"}
+    # cfg2 (262,144 particles) has the sample's k / latent / rounds: its CPU forward is the sample's rate on 16x the edges
+    # (BASELINE.md section 5 allows the flagged extrapolation; the whole forward would take about a minute of host time)
+    if (k, d, L, h, args.hidden_layers) == (16, 128, 10, 128, 2):
+        out["cfg2"] = {"edge_updates_per_s": out["value"], "extrapolated": True,
+                       "forward_s": round(262144 * 16 * 10 / out["value"], 1),
+                       "sample": f"extrapolated from the N={n} forward above by the edge-count ratio (same k, latent, rounds)"}
     # cfg1, complete: window -> 27-image k-NN graph (cpu_ref.preprocess) -> forward
     snap = synthetic.make_snapshot(4096, seed=1235)
     meta = synthetic.make_metadata()
@@ -210,6 +214,17 @@ def _traffic(key, kernel):
     if sha != ent.get("source_sha16"):
         return None
     return ent.get("hbm_bytes_per_launch")
+
+
+def _traffic_extra(key):
+    """Clock and matrix-pipe occupancy recorded with a traffic.json entry (same validity rule as `_traffic`)."""
+    if _traffic(key, "") is None:
+        return None
+    try:
+        ent = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[key]
+    except Exception:
+        return None
+    return {k: ent[k] for k in ("clock_ghz_under_profiler", "mfma_busy_frac", "kernel_ms_under_profiler") if k in ent} or None
 
 
 def kernel_source_sha16(name):
@@ -435,6 +450,10 @@ def main():
             roofline = {"kernel": f"{kname}<{d // 32}>", "bound": "mfma",
                         "achieved": round(tf_exec, 1), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(tf_exec / mfma_peak, 4),
                         "traffic": _traffic(f"edge_stream{'+enc' if enc_fused else ''}:{n_local}:{k}:{d}:{L}", kname),
+                        # from the same PMC passes (profiles/traffic.json): the clock the chip held under this kernel
+                        # (GRBM_GUI_ACTIVE / 8 / kernel time; the peak is quoted at 2.4 GHz) and the share of cycles the
+                        # matrix pipe was busy (SQ_VALU_MFMA_BUSY_CYCLES / SIMDs / cycles, selector MFMAs included)
+                        "pmc": _traffic_extra(f"edge_stream{'+enc' if enc_fused else ''}:{n_local}:{k}:{d}:{L}"),
                         "avg_launch_ms": round(edge_ms, 4), "launches": calls,
                         "executed_flops_per_launch": L * flops_exec + enc_flops,
                         "edge_encoder_in_launch": bool(enc_fused), "encoder_flops_per_launch": enc_flops,

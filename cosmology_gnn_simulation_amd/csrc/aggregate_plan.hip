@@ -281,9 +281,7 @@ int cgnn_aggregate_planned(const float* table, const int32_t* gather, const void
 #define CGNN_AP_GO(Kk)                                                                                              \
     {                                                                                                               \
         auto kern = aggregate_planned_kernel<Kk>;                                                                   \
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                 \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds),                    \
-                           "hipFuncSetAttribute(aggregate_planned)");                                               \
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(lds), "hipFuncSetAttribute(aggregate_planned)");                                               \
         if (rc != CGNN_OK) return rc;                                                                               \
         kern<<<(unsigned)nblocks, CGNN_AP_THREADS, lds, st>>>(table, gather, pv, fixed_k, num_nodes, width, out);    \
     }

@@ -39,6 +39,9 @@ namespace cgnn {
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 int grid_for_tiles(int64_t tiles_of_32_rows, int blocks_per_cu = 2, int waves_per_block = CGNN_WAVES_PER_BLOCK);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): the attribute is sticky, and a driver call per
+// launch is host time the launch-bound configurations and HIP-graph capture do not have
+int ensure_dynamic_lds(const void* kernel, size_t bytes, const char* what);
 
 // Persistent tile loop, XCD aware.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2),
 // so XCD x = blockIdx % 8 sweeps the contiguous x-th eighth of the tile range and its workgroups advance

@@ -114,9 +114,7 @@ static int launch_edge_lds(const MlpDev& m, size_t lds, const __bf16* ps, const 
                            int residual, hipStream_t st) {
     auto kern = edge_block_lds_kernel<HT, DT>;
     if (lds > 48 * 1024) {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                           "hipFuncSetAttribute(edge_block_lds)");
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)((int)lds), "hipFuncSetAttribute(edge_block_lds)");
         if (rc != CGNN_OK) return rc;
     }
     const int grid = grid_for_tiles((num_edges + 31) / 32, 1, CGNN_EDGE_LDS_BLOCK / 64);
@@ -226,9 +224,7 @@ static int launch_edge_n16_as(const MlpDev& m, size_t lds, const __bf16* ps, con
                               int residual, const float* x_gather, float* agg_out, int seg_k, hipStream_t st) {
     auto kern = edge_block_n16_kernel<HT, DT, BLOCK, AGG>;
     if (lds > 48 * 1024) {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                           "hipFuncSetAttribute(edge_block_n16)");
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)((int)lds), "hipFuncSetAttribute(edge_block_n16)");
         if (rc != CGNN_OK) return rc;
     }
     const int grid = grid_for_tiles((num_edges + 15) / 16, 1, BLOCK / 64);
@@ -302,9 +298,7 @@ static int launch_edge_encode_n16(const MlpDev& m, size_t lds, const float* x, i
                                   hipStream_t st) {
     auto kern = edge_encode_n16_kernel<HT, DT>;
     if (lds > 48 * 1024) {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                           "hipFuncSetAttribute(edge_encode_n16)");
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)((int)lds), "hipFuncSetAttribute(edge_encode_n16)");
         if (rc != CGNN_OK) return rc;
     }
     const int grid = grid_for_tiles((n + 15) / 16, 1, CGNN_EDGE_ENC_BLOCK / 64);
@@ -336,9 +330,7 @@ static int launch_edge(const MlpDev& m, size_t lds, const typename PRow<PREC>::e
                        int residual, hipStream_t st) {
     auto kern = edge_block_kernel<PREC, WLDS, HT, DT>;
     if (WLDS && lds > 48 * 1024) {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                           "hipFuncSetAttribute(edge_block)");
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)((int)lds), "hipFuncSetAttribute(edge_block)");
         if (rc != CGNN_OK) return rc;
     }
     const int grid = grid_for_tiles((num_edges + 31) / 32, WLDS ? 1 : 2);

@@ -231,9 +231,7 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void edge_block_f2ring_kernel(F2Edg
 template <int NH, bool RAGGED>
 static int launch_f2edge(const F2EdgeArgs& a, hipStream_t st) {
     auto kern = edge_block_f2ring_kernel<NH, RAGGED>;
-    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, f2r_edge::LDS_BYTES),
-                       "hipFuncSetAttribute(edge_block_f2ring)");
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(f2r_edge::LDS_BYTES), "hipFuncSetAttribute(edge_block_f2ring)");
     if (rc != CGNN_OK) return rc;
     const int grid = (int)(a.steps < (int64_t)num_compute_units() ? a.steps : (int64_t)num_compute_units());
     kern<<<grid, CGNN_F2R_BLOCK, f2r_edge::LDS_BYTES, st>>>(a);

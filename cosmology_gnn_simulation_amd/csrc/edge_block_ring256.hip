@@ -309,9 +309,7 @@ __global__ __launch_bounds__(CGNN_R256_BLOCK) void edge_block_ring256_kernel(Rin
 template <int NH, bool RAGGED>
 static int launch_ring256(const Ring256Args& a, hipStream_t st) {
     auto kern = edge_block_ring256_kernel<NH, RAGGED>;
-    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, r256::LDS_BYTES),
-                       "hipFuncSetAttribute(edge_block_ring256)");
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(r256::LDS_BYTES), "hipFuncSetAttribute(edge_block_ring256)");
     if (rc != CGNN_OK) return rc;
     const int grid = (int)(a.steps < (int64_t)num_compute_units() ? a.steps : (int64_t)num_compute_units());
     kern<<<grid, CGNN_R256_BLOCK, r256::LDS_BYTES, st>>>(a);

@@ -470,9 +470,7 @@ static int launch_stream(const StreamArgs& a, size_t lds, const __bf16* ps, cons
     const bool enc = a.enc_layers > 0;
     auto kern = enc ? edge_stream_n16_kernel<HT, DT, pmfma, true> : edge_stream_n16_kernel<HT, DT, pmfma, false>;
     if (lds > 48 * 1024) {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                           "hipFuncSetAttribute(edge_stream)");
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)((int)lds), "hipFuncSetAttribute(edge_stream)");
         if (rc != CGNN_OK) return rc;
     }
     const int grid = grid_for_tiles((num_edges + 15) / 16, 1, CGNN_STREAM_WAVES);

@@ -825,9 +825,7 @@ static int launch_stream32(const S32Args& a, const __bf16* ps, const __bf16* pd,
     const bool enc = a.enc_in_dim > 0;
     auto kern = enc ? edge_stream32_kernel<DT, true> : edge_stream32_kernel<DT, false>;
     if (G::LDS > 48 * 1024) {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)G::LDS),
-                           "hipFuncSetAttribute(edge_stream32)");
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)((int)G::LDS), "hipFuncSetAttribute(edge_stream32)");
         if (rc != CGNN_OK) return rc;
     }
     const int64_t pairs = ((num_edges + 31) / 32 + 1) / 2;

@@ -419,6 +419,7 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
     unsigned so_lo = 0, so_hi = 0;      // byte offsets of the rows of edges (lane >> 2) and 16 + (lane >> 2) of the tile
     auto stage_ps = [&](auto sub_c, auto i_c, const __bf16* table) __attribute__((always_inline)) {
         constexpr int SUB = decltype(sub_c)::value, i = decltype(i_c)::value;
+        (void)SUB, (void)i, (void)ps_cq;      // (used in the device pass only)
         asm volatile("" ::: "memory");
 #if defined(__HIP_DEVICE_COMPILE__)
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(table), 0, 0x7fffffff, 0x00020000);
@@ -684,15 +685,9 @@ static int launch_w8(const S32Args& a, const __bf16* ps, const __bf16* pd, int64
     typedef W8Geom<DT> W;
     const bool enc = a.enc_in_dim > 0;
     auto kern = enc ? edge_stream32w_kernel<DT, NH, true, LAG> : edge_stream32w_kernel<DT, NH, false, LAG>;
-    static bool attr_set[2][16] = {};      // per (kernel, device): the attribute is sticky, setting it costs a driver call per launch
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    if (W::LDS > 48 * 1024 && !attr_set[enc][dev]) {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)W::LDS),
-                           "hipFuncSetAttribute(edge_stream32w)");
+    if (W::LDS > 48 * 1024) {
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), W::LDS, "hipFuncSetAttribute(edge_stream32w)");
         if (rc != CGNN_OK) return rc;
-        attr_set[enc][dev] = true;
     }
     const int64_t tiles = (num_edges + 31) / 32;
     const int grid = grid_for_tiles(tiles, 1, CGNN_W8_WAVES);

@@ -129,9 +129,7 @@ static int launch_project(const void* ws, const void* wd, const float* bd, int h
     if (CAN && n >= 4096) {
         auto kern = project_kernel<PREC, PFMT, DT, HT, CAN>;
         if (2 * wbytes > 48 * 1024) {
-            int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * wbytes)),
-                               "hipFuncSetAttribute(project)");
+            int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)((int)(2 * wbytes)), "hipFuncSetAttribute(project)");
             if (rc != CGNN_OK) return rc;
         }
         const int grid = grid_for_tiles((n + 31) / 32, 2 * wbytes > 76 * 1024 ? 1 : 2);
@@ -151,9 +149,7 @@ static int launch_mlp_rows(const MlpDev& m, size_t lds, const float* x, int64_t 
                            int y_tiled, hipStream_t st) {
     auto kern = mlp_rows_kernel<PREC, WLDS, K0T, HT, OT>;
     if (WLDS && lds > 48 * 1024) {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                           "hipFuncSetAttribute(mlp_rows)");
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)((int)lds), "hipFuncSetAttribute(mlp_rows)");
         if (rc != CGNN_OK) return rc;
     }
     int grid = grid_for_tiles((n + 31) / 32, WLDS ? 1 : 2);

@@ -186,9 +186,7 @@ static int launch_node_x3(const MlpDev& m, const X3Chunks& ch, const float* b1, 
                           int64_t n, float* x_out, int residual, const float* bd, void* ps, void* pd, hipStream_t st) {
     auto kern = node_block_x3_kernel<T, PFMT>;
     const int lds = 2 * CGNN_X3_CHUNK_BYTES;
-    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds),
-                       "hipFuncSetAttribute(node_block_x3)");
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(lds), "hipFuncSetAttribute(node_block_x3)");
     if (rc != CGNN_OK) return rc;
     const int grid = grid_for_tiles((n + 31) / 32, 1);
     typedef typename PFmt<PFMT>::elem E;

@@ -293,9 +293,7 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
 template <int NH, int PFMT>
 static int launch_f2ring(const F2RingArgs& a, hipStream_t st) {
     auto kern = node_block_f2ring_kernel<NH, PFMT>;
-    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, f2r_node::LDS_BYTES),
-                       "hipFuncSetAttribute(node_block_f2ring)");
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(f2r_node::LDS_BYTES), "hipFuncSetAttribute(node_block_f2ring)");
     if (rc != CGNN_OK) return rc;
     const int grid = (int)(a.steps < (int64_t)num_compute_units() ? a.steps : (int64_t)num_compute_units());
     kern<<<grid, CGNN_F2R_BLOCK, f2r_node::LDS_BYTES, st>>>(a);

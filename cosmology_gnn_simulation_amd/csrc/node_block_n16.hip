@@ -263,9 +263,7 @@ static int launch(const MlpDev& m, const X3Chunks& ch, const float* b1, const fl
                   hipStream_t st) {
     auto kern = TERMS == 3 ? node_block_x3n16_kernel<T, PFMT> : node_block_f2n16_kernel<T, PFMT>;
     const int lds = 2 * (TERMS == 3 ? CGNN_NODE_N16_CHUNK_BYTES : CGNN_NODE_F2_CHUNK_BYTES) + (ps ? 2 * (2 * T * T) * 1024 : 0);
-    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds),
-                       "hipFuncSetAttribute(node_block_x3n16)");
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(lds), "hipFuncSetAttribute(node_block_x3n16)");
     if (rc != CGNN_OK) return rc;
     const int grid = grid_for_tiles((n + 15) / 16, CGNN_NODE_N16_BPC, CGNN_NODE_N16_BLOCK / 64);
     kern<<<grid, CGNN_NODE_N16_BLOCK, lds, st>>>(m, ch, b1, x, agg, n, x_out, residual, bd, (__bf16*)ps, (__bf16*)pd, ws_w,

@@ -3,6 +3,10 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "cgnn_common.hpp"
 
 namespace cgnn {
@@ -48,6 +52,19 @@ int grid_for_tiles(int64_t tiles, int blocks_per_cu, int waves_per_block) {
 }
 
 int num_compute_units() { return num_cus(); }
+
+int ensure_dynamic_lds(const void* kernel, size_t bytes, const char* what) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = done.find({kernel, dev});
+    if (it != done.end() && it->second >= bytes) return CGNN_OK;
+    const int rc = check_hip(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes), what);
+    if (rc == CGNN_OK) done[{kernel, dev}] = bytes;
+    return rc;
+}
 
 // ------------------------------------------------------------------ packing
 __global__ void pack_f32_kernel(const float* __restrict__ w, int out_dim, int ld, int col0, int ncols, int KT,

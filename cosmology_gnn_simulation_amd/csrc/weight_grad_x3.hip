@@ -232,9 +232,7 @@ int cgnn_weight_grad_x3(const float* g, int32_t ld_g, const float* a, int32_t ld
     rows_per_wave = (rows_per_wave + 15) / 16 * 16;
     float* part = reinterpret_cast<float*>(workspace);
     constexpr int lds = (16 * 16 * 64 + 4 * 64) * (int)sizeof(float);       // 65 KiB
-    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(weight_grad_x3_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds),
-                       "hipFuncSetAttribute(weight_grad_x3)");
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(weight_grad_x3_kernel), (size_t)(lds), "hipFuncSetAttribute(weight_grad_x3)");
     if (rc != CGNN_OK) return rc;
     weight_grad_x3_kernel<<<CGNN_WGX3_WAVES / 4, 256, lds, st>>>(g, ld_g, a, ld_a, n, rows_per_wave, part);
     rc = check_hip(hipGetLastError(), "cgnn_weight_grad_x3 launch");

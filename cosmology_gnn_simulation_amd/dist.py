@@ -142,6 +142,8 @@ def build_shard(pos_global: torch.Tensor, box_size: float, k: int, world: int, r
     margin = margin_factor * box_size * (3.0 * k / (4.0 * 3.141592653589793 * max(n_total, 1))) ** (1.0 / 3.0)
     while True:
         near = _near_tile(pos_global, box_size, lo, hi, margin) if world > 1 else None
+        if near is not None:
+            near |= owner == rank      # owner_of clamps coordinates outside [0, box) into edge tiles: owned is always searched
         whole = near is None or bool(near.all())
         sub = None if whole else torch.nonzero(near).squeeze(1)        # ascending global ids: ties order as globally
         pos_sub = pos_global if whole else pos_global[sub].contiguous()

@@ -230,10 +230,13 @@ class _PackedProcessor:
         # cat([x[src], x[dest], edge_attr]) -> [Ws | Wd | We]      (reference graph_network.py:89)
         if str(edge_precision).lower() in ("fp16x2", "f16x2", "fp32x3", "f32x3"):
             # f32 accuracy on the matrix cores: the two-fp16-term edge kernel (latent = hidden = 128, <= 3 hidden layers,
-            # f32 Ps / Pd tables); other shapes take the exact-f32 kernels
+            # f32 Ps / Pd tables); other shapes take the exact-f32 kernels.  "fp32x3" has no three-bf16-term EDGE kernel: it
+            # keeps f32's exponent range only through the exact-f32 kernels, so it is routed there (never to fp16 terms,
+            # whose range ends at 65504)
             e_lins = _split_mlp(net.edge_model)[0]
-            fits = D == 128 and w1e.shape[0] == 128 and len(e_lins) - 1 <= 3 and all(l.bias is not None for l in e_lins)
             two_terms = str(edge_precision).lower() in ("fp16x2", "f16x2")
+            fits = two_terms and D == 128 and w1e.shape[0] == 128 and len(e_lins) - 1 <= 3 and \
+                all(l.bias is not None for l in e_lins)
             proj_precision, edge_precision = ("fp16x2" if two_terms else "fp32"), ("fp16x2_n16" if fits else "fp32")
         else:
             proj_precision = edge_precision

@@ -39,6 +39,30 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
             summary.setdefault(name, {})[kn] = hbm
 
 
+def kernel_ms(name, needle):
+    """Median duration (ms) of the kernel in the PMC passes' own kernel traces."""
+    ds = []
+    for f in glob.glob(os.path.join(out, f"pmc_{name}", "p*", "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if needle in r["Kernel_Name"]:
+                ds.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    ds.sort()
+    return ds[len(ds) // 2] if ds else None
+
+
+def counters(name, needle):
+    for d in [os.path.join(out, f"pmc_{name}")]:
+        agg = collections.defaultdict(float)
+        cnt = collections.Counter()
+        for f in glob.glob(os.path.join(d, "p*", "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if needle in r["Kernel_Name"]:
+                    agg[r["Counter_Name"]] += float(r["Counter_Value"])
+                    cnt[r["Counter_Name"]] += 1
+        return {c: v / cnt[c] for c, v in agg.items()}
+    return {}
+
+
 def sha16(src):
     sys.path.insert(0, root)
     import bench            # one definition of "the source a number was measured on": the .hip file and its headers
@@ -63,6 +87,13 @@ for key, name, needle, src in (("edge_stream+enc:1000000:16:128:10", "edge_strea
     if v is not None:
         entries[key] = {"hbm_bytes_per_launch": v, "source": src, "source_sha16": sha16(src),
                         "profile": f"profiles/{os.path.basename(out).replace('profile_', '')}_pmc_summary.txt"}
+        ms, cs = kernel_ms(name, needle), counters(name, needle)
+        if ms and cs.get("GRBM_GUI_ACTIVE"):
+            cycles = cs["GRBM_GUI_ACTIVE"] / 8.0
+            entries[key]["kernel_ms_under_profiler"] = round(ms, 3)
+            entries[key]["clock_ghz_under_profiler"] = round(cycles / (ms * 1e-3) / 1e9, 3)
+            if cs.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+                entries[key]["mfma_busy_frac"] = round(cs["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cycles, 3)
 print("==== traffic.json entries")
 print(json.dumps(entries, indent=1))
 json.dump(entries, open(os.path.join(out, "traffic_entries.json"), "w"), indent=1)
