@@ -454,14 +454,16 @@ class ShardedForward:
 def build_synthetic_shard(particles_per_gpu: int, world: int, rank: int, k: int, seed: int, device, metadata: dict,
                           group=None) -> Shard:
     n_total = particles_per_gpu * world
-    snap = synthetic.make_snapshot(n_total, seed=seed)
+    # the box of synthetic.make_snapshot(n_total, seed), bit for bit, but only one global frame (positions: ownership and the
+    # neighbour search need all of them) and the feature window of the OWNED particles are built and uploaded: per rank the
+    # host work is the random draws plus N + 6 N / world elements, not the whole [6, N, 3] trajectory
+    snap = synthetic.LazySnapshot(n_total, seed=seed)
     box, dt = metadata["box_size"], metadata["dt"]
-    coords = snap["Coordinates"][:5].to(device)                     # [W, N, 3]
-    energy = snap["InternalEnergy"][:5].to(device)
-    pos = torch.remainder(coords[-1], box).contiguous()
+    W = 5
+    pos = torch.remainder(snap.frame(W - 1).to(device), box).contiguous()     # the window's last frame
     sh = build_shard(pos, box, k, world, rank)
     sh = exchange_requests(sh, group)
-    own = sh.owned_global
+    coords, energy = snap.window_of(sh.owned_global)
     # node features of the owned particles: the same kernel data_utils.preprocess uses
-    sh.x_feat, _ = ops.window_features(coords[:, own].contiguous(), energy[:, own].contiguous(), metadata, dt, box)
+    sh.x_feat, _ = ops.window_features(coords[:W].to(device).contiguous(), energy[:W].to(device).contiguous(), metadata, dt, box)
     return sh

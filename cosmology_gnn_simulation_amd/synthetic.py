@@ -41,6 +41,39 @@ def make_snapshot(num_particles: int, window: int = 5, box_size: float = 1.0, dt
                 BoxSize=torch.tensor(box_size), TimeStep=torch.tensor(dt))
 
 
+class LazySnapshot:
+    """The box of :func:`make_snapshot` (same seed -> the same numbers, bit for bit) without materialising the
+    ``[W+1, N, 3]`` trajectories: the random draws are kept (they have to be made in full to keep the generator's
+    order), single frames and the window of a SUBSET of particles are built on demand.  For the multi-GPU bench
+    (``dist.build_synthetic_shard``): every rank needs one global frame of positions for the ownership and the
+    neighbour search, but the feature window of its own particles only -- the host work and the upload per rank then
+    stay near N + N / world instead of 6 N as the job grows."""
+
+    def __init__(self, num_particles: int, window: int = 5, box_size: float = 1.0, dt: float = 0.01, seed: int = 1234):
+        g = torch.Generator().manual_seed(seed)
+        self.window, self.box_size, self.dt = window, box_size, dt
+        self.p0 = torch.rand(num_particles, 3, generator=g, dtype=torch.float32) * box_size
+        self.v = torch.randn(num_particles, 3, generator=g, dtype=torch.float32) * 0.05
+        self.noise = torch.randn(window + 1, num_particles, 1, generator=g, dtype=torch.float32)
+
+    def _coords(self, p0: torch.Tensor, v: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        coords = torch.remainder(p0.unsqueeze(0) + v.unsqueeze(0) * (self.dt * t), self.box_size)
+        return torch.where(coords >= self.box_size, coords - self.box_size, coords)
+
+    def frame(self, index: int) -> torch.Tensor:
+        """``Coordinates[index]`` of all particles, ``[N, 3]``."""
+        t = torch.tensor([float(index)], dtype=torch.float32).view(-1, 1, 1)
+        return self._coords(self.p0, self.v, t)[0]
+
+    def window_of(self, ids: torch.Tensor):
+        """``(Coordinates[:, ids], InternalEnergy[:, ids])``, all ``W + 1`` frames."""
+        ids = ids.cpu().long()
+        t = torch.arange(self.window + 1, dtype=torch.float32).view(-1, 1, 1)
+        coords = self._coords(self.p0[ids], self.v[ids], t)
+        energy = 1.0 + 0.1 * self.noise[:, ids].cumsum(dim=0)
+        return coords, energy
+
+
 def save_snapshot(path: str, snap: Dict[str, torch.Tensor]) -> None:
     np.savez(path, **{k: v.numpy() for k, v in snap.items()})
 

@@ -159,3 +159,18 @@ def test_tile_bounds_invert_owner_of():
             for a in range(3):
                 inside &= (pos[:, a] >= lo[a]) & (pos[:, a] < hi[a])
             assert torch.equal(inside, own == r)
+
+
+def test_lazy_snapshot_is_the_eager_one_bit_for_bit():
+    """dist.build_synthetic_shard builds one global frame and the owned particles' window from synthetic.LazySnapshot:
+    the same box as synthetic.make_snapshot (what the single-GPU bench and `bench.py --check` generate)."""
+    from cosmology_gnn_simulation_amd import synthetic
+    n = 50_000
+    eager = synthetic.make_snapshot(n, seed=1237)
+    lazy = synthetic.LazySnapshot(n, seed=1237)
+    for f in (0, 4, 5):
+        assert torch.equal(eager["Coordinates"][f], lazy.frame(f))
+    ids = torch.randperm(n, generator=torch.Generator().manual_seed(3))[:777]
+    coords, energy = lazy.window_of(ids)
+    assert torch.equal(eager["Coordinates"][:, ids], coords)
+    assert torch.equal(eager["InternalEnergy"][:, ids], energy)
