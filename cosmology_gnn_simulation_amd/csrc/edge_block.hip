@@ -306,9 +306,20 @@ static int launch_edge_encode_n16(const MlpDev& m, size_t lds, const float* x, i
     return check_hip(hipGetLastError(), "cgnn_mlp_rows(n16 encoder) launch");
 }
 
+int edge_encode_ring256(const MlpDev& m, const float* x, int64_t n, int ld_x, float* y, hipStream_t st,
+                        int* handled);   // edge_block_ring256.hip
+
 // Entry used by cgnn_mlp_rows (mlp_rows.hip) for CGNN_BF16_N16 weights.
 int mlp_rows_n16_encoder(const MlpDev& m, size_t lds, const float* x, int64_t n, int ld_x, float* y, hipStream_t st) {
     const int hidden = m.out_dim[0], latent = m.out_dim[m.nh];
+    if (hidden == 256 && latent == 256) {      // weights streamed through the LDS ring (they do not fit)
+        int handled = 0;
+        const int rc = edge_encode_ring256(m, x, n, ld_x, y, st, &handled);
+        if (rc != CGNN_OK || handled) return rc;
+        set_error("cgnn_mlp_rows: the 256-wide CGNN_BF16_N16 encoder takes <= 4 input features in rows of a multiple of 4 "
+                  "floats, 16-byte aligned, 1..3 hidden layers with biases and LayerNorm (got in=%d, ld=%d)", m.in_dim[0], ld_x);
+        return CGNN_ERR_UNSUPPORTED;
+    }
     if (m.in_dim[0] > 32 || hidden % 32 || latent % 32 || lds > CGNN_LDS_WEIGHT_BUDGET || m.gamma == nullptr) {
         set_error("cgnn_mlp_rows: CGNN_BF16_N16 is the edge-encoder path (input <= 32 features, LayerNorm, weights "
                   "resident in LDS)");

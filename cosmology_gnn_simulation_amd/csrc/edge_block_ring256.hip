@@ -111,6 +111,22 @@ struct FragPipe {
         buf[SLOT][2] = lds_read_b128<(1 * KS + 2 * G) * 1024>(addr);
         buf[SLOT][3] = lds_read_b128<(1 * KS + 2 * G + 1) * 1024>(addr);
     }
+    // the encoder's first Linear (K <= 32: one k-step): its chunk holds the sixteen fragments (o, k-step 0), o = 0 .. 15;
+    // a group = four consecutive output tiles
+    template <int SLOT, int G>
+    __device__ __forceinline__ void request_lin(unsigned addr) {
+        buf[SLOT][0] = lds_read_b128<(4 * G + 0) * 1024>(addr);
+        buf[SLOT][1] = lds_read_b128<(4 * G + 1) * 1024>(addr);
+        buf[SLOT][2] = lds_read_b128<(4 * G + 2) * 1024>(addr);
+        buf[SLOT][3] = lds_read_b128<(4 * G + 3) * 1024>(addr);
+    }
+    template <int SLOT, int NEWER>
+    __device__ __forceinline__ void run_lin(f32x4 (&c)[OT], bf16x8 in0, int o0) {
+        lds_wait4<NEWER>(buf[SLOT][0], buf[SLOT][1], buf[SLOT][2], buf[SLOT][3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            c[o0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, buf[SLOT][j]), in0, c[o0 + j], 0, 0, 0);
+    }
     template <int SLOT, int NEWER>
     __device__ __forceinline__ void run(f32x4 (&c)[OT], const bf16x8 (&in)[KS], int o0, int g) {
         lds_wait4<NEWER>(buf[SLOT][0], buf[SLOT][1], buf[SLOT][2], buf[SLOT][3]);
@@ -126,7 +142,7 @@ struct FragPipe {
 
 // Chunk Q of the step (see f2_ring.hpp for the protocol): the barrier vouches for chunks Q and Q + 1, chunk Q + PD starts
 // into the slot chunk Q - 1 was read from, the reads of group g + 1 go out before group g's MFMAs.
-#define CGNN_R256_CHUNK(Q, C, OP)                                                                                   \
+#define CGNN_R256_CHUNK_O(Q, O0, C, OP)                                                                             \
     {                                                                                                               \
         if ((Q) + 1 >= PD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 2) * PC) : "memory");                      \
         asm volatile("s_barrier" ::: "memory");                                                                      \
@@ -134,7 +150,7 @@ struct FragPipe {
         const unsigned cur_ = ring_lds + slot * CHUNK + lane * 16;                                                   \
         slot = slot + 1 == NS ? 0 : slot + 1;                                                                        \
         const unsigned nxt_ = ring_lds + slot * CHUNK + lane * 16;                                                   \
-        constexpr int o0_ = 2 * ((Q) % UNIT_CHUNKS);                                                                 \
+        constexpr int o0_ = (O0);                                                                                    \
         constexpr bool last_ = (Q) == NC - 1;                                                                        \
         if ((Q) == 0) pipe.template request<0, 0>(cur_);                                                             \
         pipe.template request<1, 1>(cur_);                                                                           \
@@ -146,6 +162,7 @@ struct FragPipe {
         if (!last_) pipe.template request<0, 0>(nxt_);                                                               \
         pipe.template run<1, (last_ ? 0 : 4)>(C, OP, o0_, 3);                                                        \
     }
+#define CGNN_R256_CHUNK(Q, C, OP) CGNN_R256_CHUNK_O(Q, 2 * ((Q) % UNIT_CHUNKS), C, OP)
 #define CGNN_R256_UNIT(U, C, OP)                                                                               \
     CGNN_R256_CHUNK((U) * 8 + 0, C, OP) CGNN_R256_CHUNK((U) * 8 + 1, C, OP) CGNN_R256_CHUNK((U) * 8 + 2, C, OP)  \
     CGNN_R256_CHUNK((U) * 8 + 3, C, OP) CGNN_R256_CHUNK((U) * 8 + 4, C, OP) CGNN_R256_CHUNK((U) * 8 + 5, C, OP)  \
@@ -304,6 +321,193 @@ __global__ __launch_bounds__(CGNN_R256_BLOCK) void edge_block_ring256_kernel(Rin
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+}
+
+// ---- the edge encoder at latent = hidden = 256 (reference graph_network.py:57: MLP + LayerNorm of the edge features) ----
+// Same ring, same 16-edge tiles, no P rows, no residual: chunk 0 is the whole first Linear (K <= 32 -> one k-step, sixteen
+// output tiles), then the hidden and output Linears as eight-chunk units.  The per-edge input is one aligned 16-byte
+// load (<= 4 features), requested a step ahead.  Before it the 256-wide encoder ran on the 32-row kernel with every
+// wave streaming its weights from L2: 31 ms at cfg5's shape (32 M edges).
+struct Enc256Args {
+    const char* unit[CGNN_R256_MAX_UNITS];   // packed CGNN_BF16_N16: Linear 0 (one chunk), hidden..., output
+    const float* bias[CGNN_R256_MAX_UNITS];
+    const float* gamma;
+    const float* beta;
+    const float* x;                          // [n, ld_x] edge features
+    float* y;                                // CGNN_TILED32 edge latents
+    int64_t n;
+    int64_t first_half_tile, half_tiles, steps;
+    int32_t ld_x, in_dim;
+};
+
+#define CGNN_R256E_CHUNK0(C, IN0)                                                                                   \
+    {                                                                                                               \
+        asm volatile("s_barrier" ::: "memory");                                                                      \
+        issue(PD % NC, slot == 0 ? NS - 1 : slot - 1);                                                               \
+        const unsigned cur_ = ring_lds + slot * CHUNK + lane * 16;                                                   \
+        slot = slot + 1 == NS ? 0 : slot + 1;                                                                        \
+        const unsigned nxt_ = ring_lds + slot * CHUNK + lane * 16;                                                   \
+        pipe.template request_lin<0, 0>(cur_);                                                                       \
+        pipe.template request_lin<1, 1>(cur_);                                                                       \
+        pipe.template run_lin<0, 4>(C, IN0, 0);                                                                      \
+        pipe.template request_lin<0, 2>(cur_);                                                                       \
+        pipe.template run_lin<1, 4>(C, IN0, 4);                                                                      \
+        pipe.template request_lin<1, 3>(cur_);                                                                       \
+        pipe.template run_lin<0, 4>(C, IN0, 8);                                                                      \
+        pipe.template request<0, 0>(nxt_);                                                                           \
+        pipe.template run_lin<1, 4>(C, IN0, 12);                                                                     \
+    }
+// unit U >= 1 of the encoder = chunks 1 + 8 (U - 1) .. 8 U (chunk 0 is the first Linear)
+#define CGNN_R256E_CH(U, I, C, OP) CGNN_R256_CHUNK_O(1 + 8 * ((U)-1) + (I), 2 * (I), C, OP)
+#define CGNN_R256E_UNIT(U, C, OP)                                                                       \
+    CGNN_R256E_CH(U, 0, C, OP) CGNN_R256E_CH(U, 1, C, OP) CGNN_R256E_CH(U, 2, C, OP) CGNN_R256E_CH(U, 3, C, OP) \
+    CGNN_R256E_CH(U, 4, C, OP) CGNN_R256E_CH(U, 5, C, OP) CGNN_R256E_CH(U, 6, C, OP) CGNN_R256E_CH(U, 7, C, OP)
+
+template <int NH, bool RAGGED>
+__global__ __launch_bounds__(CGNN_R256_BLOCK) void edge_encode_ring256_kernel(Enc256Args a) {
+    using namespace r256;
+    constexpr int NC = 1 + NH * UNIT_CHUNKS;
+    static_assert(NH + 1 <= CGNN_R256_MAX_UNITS && UNIT_CHUNKS == 8 && NC > PD, "layer count / chunking");
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    {   // resident: bias of Linear 0 .. NH at vec[l], LayerNorm vectors behind them
+        float* vec = reinterpret_cast<float*>(cgnn_smem);
+        for (int i = threadIdx.x; i < D; i += blockDim.x) {
+#pragma unroll
+            for (int l = 0; l <= NH; ++l) vec[l * D + i] = a.bias[l][i];
+            vec[(NH + 1) * D + i] = a.gamma[i];
+            vec[(NH + 2) * D + i] = a.beta[i];
+        }
+    }
+    __syncthreads();
+    const LdsVecPtr vec = (LdsVecPtr)cgnn_smem;
+    const unsigned ring_lds = (unsigned)(uintptr_t)(cgnn_smem + RING_OFF);
+
+    const unsigned voff = (unsigned)wave * 1024u + (unsigned)lane * 16u;
+    int slot = 0;
+    auto issue = [&](int chunk, int into_slot) {
+        const char* src = chunk == 0 ? a.unit[0] : a.unit[1 + (chunk - 1) / UNIT_CHUNKS] + ((chunk - 1) % UNIT_CHUNKS) * CHUNK;
+#pragma unroll
+        for (int i = 0; i < PC; ++i)
+            dma_piece(src + i * (WAVES * 1024), voff, ring_lds + into_slot * CHUNK + (wave + WAVES * i) * 1024);
+    };
+#pragma unroll
+    for (int i = 0; i < PD; ++i) issue(i, i);
+
+    const int64_t last_ht = a.half_tiles - 1;
+    auto row_of = [&](int64_t ht) {      // the lane's edge: its feature row's address
+        const int64_t ht_c = RAGGED && ht > last_ht ? last_ht : ht;
+        const int64_t e = ht_c * 16 + c;
+        return a.x + (e < a.n ? e : a.n - 1) * a.ld_x;
+    };
+    const int nb = gridDim.x;
+    int64_t step = blockIdx.x;
+    u32x4 xn = load16<0>(row_of(a.first_half_tile + step * WAVES + wave));
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn)::"memory");
+
+    for (; step < a.steps; step += nb) {
+        const int64_t ht_raw = a.first_half_tile + step * WAVES + wave;
+        const bool valid = !RAGGED || ht_raw <= last_ht;           // wave-uniform
+        const int64_t ht = RAGGED && ht_raw > last_ht ? last_ht : ht_raw;
+        const int64_t next_step = step + nb < a.steps ? step + nb : step;
+
+        FragPipe pipe;
+        f32x4 acc[OT];
+        bf16x8 op[KS];
+        bf16x8 in0;
+        {   // k-step 0 of the N16 operand: element j of lane (c, q) is feature 16 (j >> 2) + 4 q + (j & 3): features 0 .. 3 sit
+            // in elements 0 .. 3 of the q = 0 lanes
+            const f32x4 xv = __builtin_bit_cast(f32x4, xn);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) in0[j] = (__bf16)((j < 4 && q == 0 && j < a.in_dim) ? xv[j & 3] : 0.f);
+        }
+        fill16<OT>(acc, vec, q);
+        CGNN_R256E_CHUNK0(acc, in0)
+        operand16<true, KS>(op, acc);
+        if constexpr (NH >= 2) {
+            fill16<OT>(acc, vec + 1 * D, q);
+            CGNN_R256E_UNIT(1, acc, op)
+            operand16<true, KS>(op, acc);
+        }
+        if constexpr (NH >= 3) {
+            fill16<OT>(acc, vec + 2 * D, q);
+            CGNN_R256E_UNIT(2, acc, op)
+            operand16<true, KS>(op, acc);
+        }
+        fill16<OT>(acc, vec + NH * D, q);
+        CGNN_R256E_UNIT(NH, acc, op)
+
+        // ---- tail: the next tile's features, LayerNorm, stores ----
+        int tl = threadIdx.x & 63;
+        asm volatile("" : "+v"(tl));
+        const int tc = tl & 15, tq = tl >> 4;
+        xn = load16<0>(row_of(a.first_half_tile + next_step * WAVES + wave));
+        layer_norm16<OT>(acc, vec + (NH + 1) * D, vec + (NH + 2) * D, tq);
+        const int64_t tb = (ht >> 1) * (32 * D) + n16_lane_offset(tc, tq, (int)(ht & 1));
+        if (valid) {
+#pragma unroll
+            for (int o = 0; o < OT; ++o) *reinterpret_cast<f32x4*>(a.y + tb + n16_tile_offset(o)) = acc[o];
+        }
+        // the feature load is older than the stores: everything behind it may stay in flight (a wave past the end of a
+        // ragged step issues no stores: it drains)
+        if (RAGGED)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn)::"memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xn) : "n"(OT) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+template <int NH, bool RAGGED>
+static int launch_enc256(const Enc256Args& a, hipStream_t st) {
+    auto kern = edge_encode_ring256_kernel<NH, RAGGED>;
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(r256::LDS_BYTES), "hipFuncSetAttribute(edge_encode_ring256)");
+    if (rc != CGNN_OK) return rc;
+    const int grid = (int)(a.steps < (int64_t)num_compute_units() ? a.steps : (int64_t)num_compute_units());
+    kern<<<grid, CGNN_R256_BLOCK, r256::LDS_BYTES, st>>>(a);
+    return check_hip(hipGetLastError(), "cgnn_mlp_rows(ring 256 encoder) launch");
+}
+
+// Called by cgnn_mlp_rows (through mlp_rows_n16_encoder, edge_block.hip) for a CGNN_BF16_N16 encoder with latent = hidden =
+// 256.  *handled = 0: the shape or the feature layout is not this kernel's (nothing launched).
+int edge_encode_ring256(const MlpDev& m, const float* x, int64_t n, int ld_x, float* y, hipStream_t st, int* handled) {
+    *handled = 0;
+    if (m.nh < 1 || m.nh > 3 || !m.gamma || !m.beta || m.in_dim[0] > 4 || (ld_x & 3) != 0 || ((uintptr_t)x & 15) != 0 || n <= 0)
+        return CGNN_OK;
+    Enc256Args a;
+    memset(&a, 0, sizeof(a));
+    for (int l = 0; l <= m.nh; ++l) {
+        a.unit[l] = reinterpret_cast<const char*>(m.w[l]);
+        a.bias[l] = m.b[l];
+        if (!m.b[l]) return CGNN_OK;
+    }
+    a.gamma = m.gamma;
+    a.beta = m.beta;
+    a.x = x;
+    a.y = y;
+    a.n = n;
+    a.ld_x = ld_x;
+    a.in_dim = m.in_dim[0];
+    a.half_tiles = 2 * ((n + 31) / 32);
+    const int64_t full = a.half_tiles / 8;
+    int rc = CGNN_OK;
+#define CGNN_GO(NHh, RAG) \
+    if (rc == CGNN_OK && m.nh == NHh) rc = launch_enc256<NHh, RAG>(a, st);
+    if (full > 0) {
+        a.first_half_tile = 0;
+        a.steps = full;
+        CGNN_GO(1, false) CGNN_GO(2, false) CGNN_GO(3, false)
+    }
+    if (rc == CGNN_OK && a.half_tiles % 8 != 0) {
+        a.first_half_tile = full * 8;
+        a.steps = 1;
+        CGNN_GO(1, true) CGNN_GO(2, true) CGNN_GO(3, true)
+    }
+#undef CGNN_GO
+    if (rc == CGNN_OK) *handled = 1;
+    return rc;
 }
 
 template <int NH, bool RAGGED>

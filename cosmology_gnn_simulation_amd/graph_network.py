@@ -462,8 +462,13 @@ class EncodeProcessDecode(nn.Module):
                   ops._prec(self.edge_precision) == _lib.BF16 and ops.StreamImage.supported(D, H, nh, L))
         enc_edge = _pack_mlp(self.encoder.edge_model, self.edge_precision)
         enc_in_image = tile32 and ops.StreamImage.supported(D, H, nh, L, enc_edge.in_dim)
-        if not tile32 and enc_edge.precision == _lib.BF16 and enc_edge.in_dim <= 32 and D <= 128 and \
-                enc_edge.hidden <= 128 and enc_edge.lds_bytes() <= _lib.LDS_WEIGHT_BUDGET:
+        enc_lins = _split_mlp(self.encoder.edge_model)[0]
+        # latent = hidden = 256: the encoder's weights stream through the LDS ring of the 256-wide edge kernel
+        # (edge_block_ring256.hip), which reads an edge's features with one aligned 16-byte load: exactly 4 of them
+        wide_enc = D == 256 and enc_edge.hidden == 256 and enc_edge.in_dim == 4 and enc_edge.num_hidden_layers <= 3 and \
+            all(l.bias is not None for l in enc_lins)
+        if not tile32 and enc_edge.precision == _lib.BF16 and enc_edge.in_dim <= 32 and (wide_enc or (
+                D <= 128 and enc_edge.hidden <= 128 and enc_edge.lds_bytes() <= _lib.LDS_WEIGHT_BUDGET)):
             enc_edge = _pack_mlp(self.encoder.edge_model, "bf16_n16")    # 16-edge-per-wave encoder, TILED32 output
         rounds = [_PackedProcessor(net, D, self.edge_precision, self.node_precision, keep_32_row_edges=tile32)
                   for net in self.processor]

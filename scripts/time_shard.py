@@ -61,12 +61,26 @@ run = cdist.ShardedForward(m, sh, halo=NoExchange())
 for _ in range(2):
     run()
 torch.cuda.synchronize()
+# host side alone: how long the launches of one forward take to ENQUEUE (no synchronisation inside; the device is busy with
+# the forwards before it, so this is the host's own cost per forward -- the floor of a launch-bound rank)
+t1 = time.perf_counter()
+host = []
+for _ in range(a.iters):
+    h0 = time.perf_counter()
+    run()
+    host.append(time.perf_counter() - h0)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t1) / a.iters
 with ops.OpTimer() as tm:
-    t1 = time.perf_counter()
     for _ in range(a.iters):
         run()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t1) / a.iters
-print(f"forward of this rank, no exchange: {dt * 1e3:.2f} ms = {sh.n_owned * a.neighbors * L / dt / 1e9:.2f} G edge-updates/s")
-for name, (c, ms) in sorted(tm.summary().items()):
+summ = tm.summary()
+kern = sum(ms for _, ms in summ.values()) / a.iters
+calls = sum(c for c, _ in summ.values()) // a.iters
+host_ms = sorted(host)[len(host) // 2] * 1e3
+print(f"forward of this rank, no exchange: {dt * 1e3:.2f} ms = {sh.n_owned * a.neighbors * L / dt / 1e9:.2f} G edge-updates/s; "
+      f"kernels {kern:.2f} ms in {calls} library calls; host enqueue {host_ms:.2f} ms per forward "
+      f"({'launch-bound' if host_ms > 0.85 * dt * 1e3 else 'the device is the limit'})")
+for name, (c, ms) in sorted(summ.items()):
     print(f"   {name:16s} {c // a.iters:4d} calls  {ms / a.iters:8.3f} ms per forward")

@@ -103,3 +103,41 @@ def test_edge_ring_kernels_repeat_bit_identically(fmt, d, k, n):
         got = ops.edge_block(mlp, ps, pd, src, dst, et, None, None, True).buf
         torch.cuda.synchronize()
         assert torch.equal(got, first), f"run {it} differs"
+
+
+@pytest.mark.parametrize("n,nh", [(50, 2), (128, 2), (1000, 1), (4099, 3), (70_003, 2)])
+def test_edge_encoder_at_latent_256_through_the_ring(n, nh):
+    """Reference graph_network.py:57 at latent = hidden = 256: cgnn_mlp_rows with CGNN_BF16_N16 weights streams them through
+    the LDS ring of the 256-wide edge kernel (edge_block_ring256.hip).  Against a torch emulation of its arithmetic (bf16
+    operands, wide accumulation, f32 LayerNorm), and against the 32-row kernel on the same bf16 weights."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(256 + n + nh)
+    d = 256
+    dims = [4] + [d] * nh + [d]
+    lin = []
+    for i in range(nh + 1):
+        bound = 1.0 / dims[i] ** 0.5
+        lin.append((((torch.rand(dims[i + 1], dims[i], generator=gen) * 2 - 1) * bound).to(DEV),
+                    ((torch.rand(dims[i + 1], generator=gen) * 2 - 1) * bound).to(DEV)))
+    ln = ((1 + 0.1 * torch.randn(d, generator=gen)).to(DEV), (0.1 * torch.randn(d, generator=gen)).to(DEV))
+    attr = (torch.randn(n, 4, generator=gen) * 0.5).to(DEV)
+    bf = lambda t: t.bfloat16().float()                                        # noqa: E731
+    dot = lambda a, w: (bf(a).double() @ bf(w).double().t()).float()           # noqa: E731
+    h = dot(attr, lin[0][0]) + lin[0][1]
+    for w, b in lin[1:]:
+        h = dot(torch.relu(h), w) + b
+    want = F.layer_norm(h, (d,), ln[0], ln[1], 1e-5)
+    ring = ops.mlp_rows(ops.PackedMLP(lin, ln, "bf16_n16"), attr, tiled=True).to_rows()
+    rows32 = ops.mlp_rows(ops.PackedMLP(lin, ln, "bf16"), attr, tiled=True).to_rows()
+    torch.cuda.synchronize()
+    assert ring.shape == want.shape and bool(torch.isfinite(ring).all())
+    scale = float(want.abs().max())
+    for got in (ring, rows32):
+        assert float((got - want).abs().max()) <= 1e-2 * scale
+        assert float((got - want).norm() / want.norm()) <= 1e-3
+    # every row, not just the norm: one wrong 16-edge tile must not hide among 70,000 edges
+    per_row = (ring - want).norm(dim=1) / want.norm(dim=1)
+    assert float(per_row.max()) <= 1e-2, int(per_row.argmax())
+    # a second run returns the same bits (ring protocol: no read of a chunk that has not landed)
+    again = ops.mlp_rows(ops.PackedMLP(lin, ln, "bf16_n16"), attr, tiled=True).to_rows()
+    assert torch.equal(ring, again)
