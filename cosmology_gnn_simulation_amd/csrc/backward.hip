@@ -423,10 +423,15 @@ int cgnn_mlp_backward(const cgnn_mlp* fwd, const cgnn_linear* fwd_part2, const c
     // square models hidden == latent in {32, 64, 128, 256}: node block (two inputs), encoder (narrow input), decoder
 #define CGNN_BWD_T(Tt) CGNN_BWD(Tt, Tt, Tt, Tt) CGNN_BWD(1, 0, Tt, Tt) CGNN_BWD(Tt, 0, Tt, 1)
     CGNN_BWD_T(1) CGNN_BWD_T(2) CGNN_BWD_T(4) CGNN_BWD_T(8)
+    // mlp_hidden_size != latent_size (reference config.py:19-20 and train.py:165-171 pass them independently): the pairs the
+    // forward kernels are compiled for (CGNN_FOR_EACH_PAIR): hidden 128 with latent 64 or 256
+#define CGNN_BWD_M(Lt) CGNN_BWD(Lt, Lt, 4, Lt) CGNN_BWD(1, 0, 4, Lt) CGNN_BWD(Lt, 0, 4, 1)
+    CGNN_BWD_M(2) CGNN_BWD_M(8)
+#undef CGNN_BWD_M
 #undef CGNN_BWD_T
 #undef CGNN_BWD
     set_error("cgnn_mlp_backward: no kernel for in=(%d,%d) hidden=%d out=%d (training is built for hidden == latent in "
-              "{32,64,128,256})", in1, in2, hidden, out_dim);
+              "{32,64,128,256} and for hidden 128 with latent 64 or 256)", in1, in2, hidden, out_dim);
     return CGNN_ERR_UNSUPPORTED;
 }
 

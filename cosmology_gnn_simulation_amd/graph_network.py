@@ -586,7 +586,16 @@ class EncodeProcessDecode(nn.Module):
                 g._cgnn_by_sender = cached
             except Exception:
                 pass
+        packs.edge_stream_fn = None
+        if getattr(self, "train_edge_stream", False):
+            # like-for-like with the reference's step, which computes the edge stream although nothing reads it
+            ea = edge_attr.detach().float().contiguous()
+            if plan is not None:
+                ea = ops.gather_rows(ea.view(n, -1), order).view(n * fixed_k, -1)
+            node_in = x.shape[1]
+            packs.edge_stream_fn = lambda xs: training.edge_stream_of(self, xs, src, dst, fixed_k, ea, node_in)
         acc, tr = training.forward_train(self, x, src, dst, fixed_k, packs, cached[1])
+        packs.edge_stream_fn = None
         if plan is not None:
             acc = training.permute_rows(acc, inv, order)
             tr = training.permute_rows(tr, inv, order)

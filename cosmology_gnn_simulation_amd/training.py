@@ -8,7 +8,9 @@ stream never reaches the outputs.  The autograd graph from the loss 
     acceleration = dec_acc(x_L),  temp_rate = dec_tr(x_L)
 
 and every edge-model parameter keeps ``grad = None`` under the reference as well.  This module runs exactly that
-graph in exact f32: the training forward skips the (dead) edge stream, keeps ``x_i`` and ``agg_i`` per round, and the backward
+graph in exact f32: the training forward SKIPS the (dead) edge stream -- every step time quoted for it carries that label;
+``model.train_edge_stream = True`` runs the edge stream's forward as well (the reference computes it although nothing
+reads it), for a like-for-like step time -- keeps ``x_i`` and ``agg_i`` per round, and the backward
 recomputes the activations tile by tile (``cgnn_mlp_backward``), transposes the aggregation by gathering through
 the sender-major adjacency (``cgnn_csr_build`` once per graph, ``cgnn_aggregate_csr``) and reduces the parameter
 gradients with ``cgnn_weight_grad`` / ``cgnn_col_dot``.
@@ -123,13 +125,18 @@ class TrainPacks:
         self.dec_acc = _TrainMLP(*_split_mlp(model.decoder_acc), precision=prec, latent_input=True)
         self.dec_tr = _TrainMLP(*_split_mlp(model.decoder_temp_rate), precision=prec, latent_input=True)
         self.all = [self.enc] + self.rounds + [self.dec_acc, self.dec_tr]
+        self.hidden = self.enc.hidden
+        # the (hidden, latent) pairs the kernels are compiled for (CGNN_FOR_EACH_PAIR): squares, and hidden 128 with latent
+        # 64 or 256 -- the reference passes the two sizes independently (config.py:19-20, train.py:165-171)
+        pair_ok = (self.hidden == D and D in (32, 64, 128, 256)) or (self.hidden == 128 and D in (64, 256))
         for m in self.all:
-            if m.hidden != D or m.hidden not in (32, 64, 128, 256):
-                raise CgnnError(f"training kernels are built for mlp_hidden_size == latent_size in (32, 64, 128, 256); got "
-                                f"hidden {m.hidden}, latent {D}")
+            if m.hidden != self.hidden or not pair_ok:
+                raise CgnnError(f"training kernels are built for mlp_hidden_size == latent_size in (32, 64, 128, 256) and for "
+                                f"mlp_hidden_size 128 with latent_size 64 or 256; got hidden {m.hidden}, latent {D}")
         if self.enc.in1 > 32:
             raise CgnnError(f"training kernels take at most 32 node input features (got {self.enc.in1})")
         self.nh = self.enc.nh
+        self.edge_stream_fn = None      # set per call by EncodeProcessDecode._forward_train when model.train_edge_stream
 
     def params(self) -> List[torch.Tensor]:
         return [p for m in self.all for p in m.params()]
@@ -153,6 +160,8 @@ class _NodeStream(torch.autograd.Function):
             xs.append(ops.node_block(r.run, r.run.layers[0], r.run2, x, agg, None, residual=True))
         acc = ops.mlp_rows(packs.dec_acc.run, xs[-1])
         tr = ops.mlp_rows(packs.dec_tr.run, xs[-1])
+        if packs.edge_stream_fn is not None:      # model.train_edge_stream: the (dead) edge stream, for like-for-like step times
+            packs.edge_stream_fn(xs)
         ctx.packs, ctx.graph, ctx.x0, ctx.xs, ctx.aggs = packs, graph, x0, xs, aggs
         return acc, tr
 
@@ -161,7 +170,7 @@ class _NodeStream(torch.autograd.Function):
     def backward(ctx, d_acc, d_tr):
         packs, (src, dst, fixed_k, by_sender), x0, xs = ctx.packs, ctx.graph, ctx.x0, ctx.xs
         n, D = x0.shape[0], packs.latent
-        scratch = ops.BackwardScratch(n, D, max(D, 32), packs.nh, x0.device)
+        scratch = ops.BackwardScratch(n, packs.hidden, max(D, 32), packs.nh, x0.device)
         grads_of = {}
         xl = xs[-1]
         zero = lambda t, w: torch.zeros((n, w), dtype=torch.float32, device=x0.device) if t is None else t  # noqa: E731
@@ -182,6 +191,34 @@ class _NodeStream(torch.autograd.Function):
         flat = [g for m in packs.all for g in grads_of[id(m)]]
         ctx.xs = None
         return (None, None, dx0, *flat)
+
+
+def edge_stream_of(model, xs: Sequence[torch.Tensor], src: torch.Tensor, dst: torch.Tensor, fixed_k: int,
+                   edge_attr: torch.Tensor, node_in: int):
+    """The edge stream the training forward otherwise skips (under the reference nothing reads it, but its
+    forward is computed -- reference graph_network.py:89-90, :182): the inference kernels at the model's ``edge_precision``
+    on the node latents ``xs[i]`` of every round.  No gradient passes through it.  Returns the final edge latents."""
+    from . import graph_network as gn
+    with torch.no_grad():
+        P = model._pack(node_in, edge_attr.shape[1])
+        rounds = P["rounds"]
+        n = xs[0].shape[0]
+        image = P["image"]
+        if image is not None:
+            H = rounds[0].ws.out_dim
+            ps_all = torch.empty((len(rounds), n, H), dtype=torch.bfloat16, device=xs[0].device)
+            pd_all = torch.empty_like(ps_all)
+            for i, p in enumerate(rounds):
+                ops.project_nodes(p.ws, p.wd, xs[i], ps_all[i], pd_all[i], p.p_format)
+            img, kernel = model._edge_stream_plan(P, fixed_k, src.numel(), edge_attr)
+            e0 = None if img.enc_in else ops.mlp_rows(P["enc_edge"], edge_attr, tiled=True)
+            return ops.edge_stream_run(img, ps_all, pd_all, src, dst, e0, e0, edge_attr if img.enc_in else None,
+                                       kernel=kernel, lag=int(getattr(model, "edge_stream_lag", 0)), fixed_k=fixed_k)
+        e = ops.mlp_rows(P["enc_edge"], edge_attr, tiled=True)
+        for i, p in enumerate(rounds):
+            ps, pd = ops.project_nodes(p.ws, p.wd, xs[i], None, None, p.p_format)
+            e = ops.edge_block(p.edge, ps, pd, src, dst, e, e, None, True)
+        return e
 
 
 def forward_train(model, x0: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, fixed_k: int, packs: TrainPacks,

@@ -82,7 +82,9 @@ for key, name, needle, src in (("edge_stream+enc:1000000:16:128:10", "edge_strea
                                ("aggregate:1000000:16:128", "aggregate_planned", "aggregate_planned", "aggregate_plan.hip"),
                                ("aggregate_plain:1000000:16:128", "aggregate", "aggregate_fixedk", "runtime.hip"),
                                ("scatter_shuffled:1000000:16:128", "scatter", "aggregate_scatter", "runtime.hip"),
-                               ("edge_block:262144:16:128:fp16x2", "edge_block_f2", "edge_block_f2ring", "edge_block_f2.hip")):
+                               ("edge_block:262144:16:128:fp16x2", "edge_block_f2", "edge_block_f2ring", "edge_block_f2.hip"),
+                               ("edge_block:1000000:32:256:bf16", "edge_block_256", "edge_block_ring256", "edge_block_ring256.hip"),
+                               ("edge_stream+enc:4000000:16:128:10", "edge_stream_4m", "edge_stream32w", "edge_stream32w.hip")):
     v = pick(name, needle)
     if v is not None:
         entries[key] = {"hbm_bytes_per_launch": v, "source": src, "source_sha16": sha16(src),

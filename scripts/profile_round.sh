@@ -35,5 +35,8 @@ echo "== general scatter-add (shuffled edge list: one atomic row per edge)"
 pmc scatter scatter_shuffled --real-graph -- "${TRAFFIC[@]}"
 echo "== f32-accuracy edge block (cfg2 size)"
 pmc edge_block_f2 edge_block --particles 262144 --edge-precision fp16x2 --node-precision fp16x2 -- "${TRAFFIC[@]}" "${SQ[0]}"
+echo "== 256-wide edge block (cfg5's shape: 1 M particles, k = 32) and the edge stream at cfg4's size (4 M particles)"
+pmc edge_block_256 edge_block --particles 1000000 --neighbors 32 --latent 256 --edge-precision bf16 --node-precision fp16x2 -- "${TRAFFIC[@]}" "${SQ[0]}"
+pmc edge_stream_4m edge_stream --particles 4000000 --real-graph --edge-precision bf16 --node-precision fp16x2 -- "${TRAFFIC[@]}"
 python3 $REPO/scripts/profile_collect.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

@@ -45,7 +45,10 @@ class _Lin:   # what training._TrainMLP needs from an nn.Linear / nn.LayerNorm
     (1, 17, 0, 32, 32, 2, True), (1000, 21, 0, 64, 64, 2, True), (333, 17, 0, 128, 128, 1, True),
     (257, 128, 0, 128, 3, 2, False), (64, 64, 0, 64, 1, 3, False), (4100, 128, 128, 128, 128, 2, True),
     (95, 32, 32, 32, 32, 1, True), (700, 64, 64, 64, 64, 3, True),
-    (200, 17, 0, 256, 256, 2, True), (300, 256, 256, 256, 256, 2, True), (150, 256, 0, 256, 3, 2, False)])   # latent 256 (cfg5)
+    (200, 17, 0, 256, 256, 2, True), (300, 256, 256, 256, 256, 2, True), (150, 256, 0, 256, 3, 2, False),    # latent 256 (cfg5)
+    # mlp_hidden_size != latent_size (reference config.py:19-20): hidden 128 with latent 64 / 256 -- encoder, round, decoder
+    (500, 17, 0, 128, 64, 2, True), (400, 64, 64, 128, 64, 2, True), (300, 64, 0, 128, 3, 2, False),
+    (200, 17, 0, 128, 256, 2, True), (300, 256, 256, 128, 256, 1, True), (150, 256, 0, 128, 1, 3, False)])
 @pytest.mark.parametrize("precision", ["fp32", "fp32x3", "fp32x3 with the forward recomputed on fp16x2"])
 def test_mlp_backward_matches_autograd(n, fin, fin2, hid, out, nh, ln, precision):
     """cgnn_mlp_backward + the parameter-gradient reductions of one MLP against torch autograd on the oracle: exact f32,
@@ -66,7 +69,7 @@ def test_mlp_backward_matches_autograd(n, fin, fin2, hid, out, nh, ln, precision
     lnm = _Lin(sd["m.1.weight"].detach().to(DEV), sd["m.1.bias"].detach().to(DEV)) if ln else None
     tm = _TrainMLP(lins, lnm, split_at=fin if fin2 else None, precision=precision, latent_input=latent_input)
     assert (tm.rec.precision == _lib.F16X2) == latent_input
-    scratch = ops.BackwardScratch(n, hid, max(hid, 32), nh, DEV)
+    scratch = ops.BackwardScratch(n, hid, max(hid, out, 32), nh, DEV)
     ud = u.detach().to(DEV)
     u1 = ud[:, :fin].contiguous()
     u2 = ud[:, fin:].contiguous() if fin2 else None
@@ -143,12 +146,12 @@ def test_weight_grad_x3_abi_rejects_what_it_cannot_take():
 def test_mlp_backward_rejects_unsupported_shapes():
     from cosmology_gnn_simulation_amd.training import _TrainMLP
     gen = torch.Generator().manual_seed(0)
-    sd = _rand_mlp(gen, 17, 128, 64, 2, True)             # hidden != latent: the backward is built for square models
+    sd = _rand_mlp(gen, 17, 64, 128, 2, True)             # hidden 64, latent 128: not a pair the kernels are compiled for
     lins = [_Lin(sd[f"m.0.{2 * i}.weight"].to(DEV), sd[f"m.0.{2 * i}.bias"].to(DEV)) for i in range(3)]
     tm = _TrainMLP(lins, _Lin(sd["m.1.weight"].to(DEV), sd["m.1.bias"].to(DEV)))
-    scratch = ops.BackwardScratch(8, 128, 64, 2, DEV)
+    scratch = ops.BackwardScratch(8, 64, 128, 2, DEV)
     with pytest.raises(ops.CgnnError, match="no kernel"):
-        tm.backward(torch.zeros(8, 17, device=DEV), None, torch.zeros(8, 64, device=DEV), scratch, True)
+        tm.backward(torch.zeros(8, 17, device=DEV), None, torch.zeros(8, 128, device=DEV), scratch, True)
 
 
 @pytest.mark.parametrize("n,e,width", [(500, 8000, 128), (300, 4800, 64), (10, 0, 32), (7, 1, 4), (64, 5000, 32)])
@@ -287,6 +290,43 @@ def test_training_step_gradients_match_reference_autograd(n, k, latent, nh, step
             assert _close(got[name].grad, ref.grad, gtol if ref.grad.numel() > 1 else 5 * gtol), name
 
 
+@pytest.mark.parametrize("n,k,latent,hidden,nh,steps", [(700, 8, 64, 128, 2, 3), (400, 16, 256, 128, 2, 2)])
+@pytest.mark.parametrize("train_precision", ["fp32", "fp32x3"])
+def test_training_step_with_hidden_size_other_than_latent(n, k, latent, hidden, nh, steps, train_precision):
+    """The reference passes latent_size and mlp_hidden_size independently (config.py:19-20, train.py:165-171): a training
+    step with hidden 128 and latent 64 / 256 against torch autograd on the oracle, same gates as the square models."""
+    window, seed = 5, n
+    snap = synthetic.make_snapshot(n, window, seed=seed)
+    meta = synthetic.make_metadata()
+    c, e = snap["Coordinates"], snap["InternalEnergy"]
+    dt = 0.01
+    g = data_utils.preprocess(c[:window].clone(), e[:window].clone(), meta, c[window].clone(), e[window].clone(), 0.0, k,
+                              dt, 1.0)
+    sd = synthetic.make_state_dict(latent, hidden, nh, steps, 3, node_in=g.x.shape[1], edge_in=4, seed=seed + 1)
+    want_loss, sdr, want_dx, want_out = _reference_grads(sd, g, nh, steps, dt)
+    model = graph_network.EncodeProcessDecode(latent, hidden, nh, steps, 3)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    model.train_precision = train_precision
+    g.x.requires_grad_(True)
+    pred = model(g)
+    mse = torch.nn.functional.mse_loss
+    loss = (mse(pred["acceleration"], g.y_acc) + 0.5 * mse(pred["temp_rate"], g.y_temp_rate)
+            + losses.momentum_conservation_loss(pred["acceleration"], g, dt, 0.1))
+    loss.backward()
+    assert _close(pred["acceleration"], want_out["acceleration"], 1e-5)
+    assert _close(pred["temp_rate"], want_out["temp_rate"], 1e-5)
+    gtol = GTOL if latent <= 128 else 1.5 * GTOL
+    assert _close(g.x.grad, want_dx, gtol)
+    got = dict(model.named_parameters())
+    for name, ref in sdr.items():
+        if ".edge_model." in name:
+            assert ref.grad is None and got[name].grad is None, name
+        else:
+            assert got[name].grad is not None and got[name].grad.shape == ref.grad.shape, name
+            assert _close(got[name].grad, ref.grad, gtol if ref.grad.numel() > 1 else 5 * gtol), name
+
+
 def test_training_on_a_batch_of_graphs_and_optimizer_step():
     """train.py:233-264 shape: several graphs batched, Adam step, second forward sees the updated weights."""
     graphs, sd, dt = [], None, None
@@ -341,3 +381,32 @@ def test_training_rejects_edge_message_source():
         model(g)
     with torch.no_grad():
         model(g)                                       # inference in that mode still works
+
+
+def test_training_with_the_edge_stream_switched_on_changes_no_output_and_no_gradient():
+    """model.train_edge_stream runs the edge stream's forward inside the training step (the reference computes it although
+    nothing reads it; the default skips it and every step time quoted says so): outputs and gradients keep
+    their bits, and the stream it runs is the inference one."""
+    g, sd, dt = _problem(700, 16, 128, 2, 3, seed=21)
+    outs = []
+    for on in (False, True):
+        model = graph_network.EncodeProcessDecode(128, 128, 2, 3, 3)
+        model.load_state_dict(sd)
+        model = model.to(DEV).train()
+        model.edge_precision, model.node_precision = "bf16", "fp16x2"
+        model.train_edge_stream = on
+        pred = model(g)
+        (pred["acceleration"].square().mean() + pred["temp_rate"].square().mean()).backward()
+        outs.append((pred["acceleration"].detach().clone(), pred["temp_rate"].detach().clone(),
+                     {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][2].keys() == outs[1][2].keys()
+    for k in outs[0][2]:
+        assert torch.equal(outs[0][2][k], outs[1][2][k]), k
+    # what it ran: the edge stream of the inference forward on the training forward's node latents (f32 node path there,
+    # fp16x2 here: the bf16 edge operands hide the difference)
+    from cosmology_gnn_simulation_amd import training
+    model.eval()
+    with torch.no_grad():
+        ref = model.forward_with_latents(g)["edge_latent"]
+    assert bool(torch.isfinite(ref).all())
