@@ -37,13 +37,14 @@ namespace cgnn {
 #define CGNN_W8_SLOTS 3
 #define CGNN_IC(x) std::integral_constant<int, (x)> {}
 #ifndef CGNN_W8_GS
-#define CGNN_W8_GS 4       // LDS weight fragments per group
+#define CGNN_W8_GS 2       // LDS weight fragments per group (2 with two groups in flight: 17.78 against 17.98 ms with 4 / 1,
+                           // same box; 4 / 2 and an issue priority around every MFMA measured no better)
 #endif
 #ifndef CGNN_W8_LN_EARLY
 #define CGNN_W8_LN_EARLY 0    // LayerNorm affine slices (of 2 * latent / 32) done in the output layer's own step, before the barrier
 #endif
 #ifndef CGNN_W8_PD
-#define CGNN_W8_PD 1       // groups in flight ahead of the MFMAs
+#define CGNN_W8_PD 2       // groups in flight ahead of the MFMAs
 #endif
 
 #ifdef CGNN_W8_STAMPS   // developer build: per-phase cycle sums (s_memtime into scalar registers, no memory traffic inside the
