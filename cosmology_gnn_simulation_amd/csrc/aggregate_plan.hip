@@ -113,7 +113,11 @@ __global__ __launch_bounds__(CGNN_AP_THREADS) void aggregate_plan_kernel(const i
 }
 
 // One workgroup per block of 64 receivers; a 32-feature slice at a time through LDS.
-template <int K>   // 8, 16: unrolled balanced tree (cgnn_aggregate's order); 0: runtime k, left to right
+// SL: width / 32 when the slice loop is unrolled (0: runtime count) AND the table is below 4 GiB: the row loads then are
+// buffer loads without a branch (a lane without a row gets an offset past the end: no memory access, zeros) in straight-line
+// code, so that hipcc's own waits are exact counts -- with `if (row) load` in a runtime loop it waited vmcnt(0) before
+// nearly every use and the "two slices in flight" were one.
+template <int K, int SL>   // K = 8, 16: unrolled balanced tree (cgnn_aggregate's order); 0: runtime k, left to right
 __global__ __launch_bounds__(CGNN_AP_THREADS) void aggregate_planned_kernel(const float* __restrict__ table,
                                                                             const int32_t* __restrict__ gather, PlanView plan,
                                                                             int krt, int64_t num_nodes, int width,
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(CGNN_AP_THREADS) void aggregate_planned_kernel(cons
     const int U = plan.count[b];
     const int chunk = threadIdx.x & 7;            // 16-byte piece of the 128-byte slice
     const int r_lo = threadIdx.x >> 3;            // receivers r_lo and r_lo + 32 of the block
-    const int slices = width / 32;
+    const int slices = SL ? SL : width / 32;
     if (U < 0 || U > CGNN_AP_STAGE_ROWS) {   // too many distinct senders: the plain gather (same summation order)
         for (int s = 0; s < slices; ++s)
 #pragma unroll
@@ -190,24 +194,38 @@ __global__ __launch_bounds__(CGNN_AP_THREADS) void aggregate_planned_kernel(cons
     const float* const tcol = table + chunk * 4;
     // two slices in flight: slice s + 2 is requested when slice s has been copied to LDS
     f32x4 pre[2][PASSES];
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-        if (p < slices) {
+    unsigned off[PASSES];      // SL: byte offset of the lane's piece of row mine[i] (past the end: no row)
+    (void)off;
+    auto fetch = [&](f32x4 (&dstp)[PASSES], int sl) __attribute__((always_inline)) {
+        if constexpr (SL != 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(table), 0, (int)((unsigned)num_nodes * (unsigned)width * 4u), 0x00020000);
 #pragma unroll
             for (int i = 0; i < PASSES; ++i)
-                if (mine[i] >= 0) pre[p][i] = *reinterpret_cast<const f32x4*>(tcol + (int64_t)mine[i] * width + p * 32);
+                dstp[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off[i], sl * 128, 0));
+#endif
+        } else {
+#pragma unroll
+            for (int i = 0; i < PASSES; ++i)
+                if (mine[i] >= 0) dstp[i] = *reinterpret_cast<const f32x4*>(tcol + (int64_t)mine[i] * width + sl * 32);
         }
-    auto one_slice = [&](int s, auto parity) {
+    };
+    if constexpr (SL != 0) {
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i)
+            off[i] = mine[i] >= 0 ? (unsigned)mine[i] * (unsigned)width * 4u + (unsigned)chunk * 16u : 0xfffffff0u;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+        if (p < slices) fetch(pre[p], p);
+    auto one_slice = [&](int s, auto parity) __attribute__((always_inline)) {
         constexpr int P = decltype(parity)::value;
 #pragma unroll
         for (int i = 0; i < PASSES; ++i)
-            if (mine[i] >= 0) stage[(r_lo + 32 * i) * CGNN_AP_ROW_F4 + chunk] = pre[P][i];
+            if (SL != 0 || mine[i] >= 0) stage[(r_lo + 32 * i) * CGNN_AP_ROW_F4 + chunk] = pre[P][i];      // (SL: zeros for "no row")
         __syncthreads();
-        if (s + 2 < slices) {
-#pragma unroll
-            for (int i = 0; i < PASSES; ++i)
-                if (mine[i] >= 0) pre[P][i] = *reinterpret_cast<const f32x4*>(tcol + (int64_t)mine[i] * width + (s + 2) * 32);
-        }
+        if (s + 2 < slices) fetch(pre[P], s + 2);
 #pragma unroll
         for (int half = 0; half < HALVES; ++half) {
             const int64_t row = row0 + r_lo + 32 * half;
@@ -229,9 +247,18 @@ __global__ __launch_bounds__(CGNN_AP_THREADS) void aggregate_planned_kernel(cons
         }
         __syncthreads();                            // everybody is done reading this slice
     };
-    for (int s = 0; s < slices; s += 2) {
-        one_slice(s, std::integral_constant<int, 0>{});
-        if (s + 1 < slices) one_slice(s + 1, std::integral_constant<int, 1>{});
+    if constexpr (SL != 0) {
+        static_assert(SL % 2 == 0, "unrolled slice loop: an even count");
+#pragma unroll
+        for (int s = 0; s < SL; s += 2) {
+            one_slice(s, std::integral_constant<int, 0>{});
+            one_slice(s + 1, std::integral_constant<int, 1>{});
+        }
+    } else {
+        for (int s = 0; s < slices; s += 2) {
+            one_slice(s, std::integral_constant<int, 0>{});
+            if (s + 1 < slices) one_slice(s + 1, std::integral_constant<int, 1>{});
+        }
     }
 }
 
@@ -278,9 +305,13 @@ int cgnn_aggregate_planned(const float* table, const int32_t* gather, const void
     const PlanView pv = plan_view(const_cast<void*>(plan), nblocks);
     const int lds = CGNN_AP_STAGE_ROWS * CGNN_AP_ROW_F4 * 16;
     hipStream_t st = (hipStream_t)stream;
+    // unrolled slice loop + branch-free buffer loads: latent 128 / 256 with the table below 4 GiB (32-bit row offsets)
+    const int sl = ((int64_t)num_nodes * width * 4 < ((int64_t)1 << 32) - 16 && (width == 128 || width == 256)) ? width / 32 : 0;
 #define CGNN_AP_GO(Kk)                                                                                              \
+    if (sl == 4) CGNN_AP_GO2(Kk, 4) else if (sl == 8) CGNN_AP_GO2(Kk, 8) else CGNN_AP_GO2(Kk, 0)
+#define CGNN_AP_GO2(Kk, SLl)                                                                                        \
     {                                                                                                               \
-        auto kern = aggregate_planned_kernel<Kk>;                                                                   \
+        auto kern = aggregate_planned_kernel<Kk, SLl>;                                                              \
         int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (size_t)(lds), "hipFuncSetAttribute(aggregate_planned)");                                               \
         if (rc != CGNN_OK) return rc;                                                                               \
         kern<<<(unsigned)nblocks, CGNN_AP_THREADS, lds, st>>>(table, gather, pv, fixed_k, num_nodes, width, out);    \
@@ -289,6 +320,7 @@ int cgnn_aggregate_planned(const float* table, const int32_t* gather, const void
     else if (fixed_k == 8) CGNN_AP_GO(8)
     else CGNN_AP_GO(0)
 #undef CGNN_AP_GO
+#undef CGNN_AP_GO2
     return check_hip(hipGetLastError(), "cgnn_aggregate_planned launch");
 }
 
