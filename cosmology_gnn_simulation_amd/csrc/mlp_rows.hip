@@ -18,18 +18,27 @@ __global__ __launch_bounds__(CGNN_BLOCK) void mlp_rows_kernel(MlpDev m, const fl
     const bool in_full = (in_dim == 32 * K0T) && (ld_x % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     const bool out_full = (out_dim == 32 * OT) && (ld_y % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
     const TileRange tr = tile_range(tiles);
+    // The next tile's rows are requested as soon as this tile's have become the first operand: a workgroup with its weights in
+    // LDS is alone on its CU (one wave per SIMD), and with load -> MLP -> store in sequence per tile nothing overlapped the
+    // trip to memory.
+    f32x16 a[K0T];
+    auto load_tile_rows = [&](int64_t t) __attribute__((always_inline)) {
+        const int64_t rw = t * 32 + r;
+        const int64_t rc = rw < n ? rw : n - 1;
+        if (in_full)
+            load_rows_full<K0T>(a, x + rc * ld_x, h);
+        else
+            load_rows_ragged<K0T>(a, x + rc * ld_x, in_dim, h);
+    };
+    // (up to 128 wide: at 256 the second input tile does not fit next to the accumulators -- hundreds of spilled registers)
+    constexpr bool AHEAD = K0T <= 4 && HT <= 4 && OT <= 4;
+    if (AHEAD && tr.first < tr.end) load_tile_rows(tr.first);
     for (int64_t tile = tr.first; tile < tr.end; tile += tr.stride) {
         const int64_t row = tile * 32 + r;
-        const int64_t rowc = row < n ? row : n - 1;
         Operand<PREC, K0T> op0;
-        {
-            f32x16 a[K0T];
-            if (in_full)
-                load_rows_full<K0T>(a, x + rowc * ld_x, h);
-            else
-                load_rows_ragged<K0T>(a, x + rowc * ld_x, in_dim, h);
-            op0.template from_acc<false>(a);
-        }
+        if (!AHEAD) load_tile_rows(tile);
+        op0.template from_acc<false>(a);
+        if (AHEAD && tile + tr.stride < tr.end) load_tile_rows(tile + tr.stride);
         Operand<PREC, HT> oph;
         {
             f32x16 acc[HT];
