@@ -37,7 +37,7 @@ EXPORTS = (
     "cgnn_mlp_backward", "cgnn_weight_grad", "cgnn_weight_grad_x3_workspace_bytes", "cgnn_weight_grad_x3",
     "cgnn_col_dot", "cgnn_col_dot2", "cgnn_csr_workspace_bytes", "cgnn_csr_build",
     "cgnn_aggregate_csr", "cgnn_aggregate_csr_add", "cgnn_edge_stream", "cgnn_edge_stream_image_bytes", "cgnn_edge_stream_image_build",
-    "cgnn_edge_stream_run", "cgnn_edge_stream_w8_supported", "cgnn_edge_stream_image_build_w8", "cgnn_edge_stream_run_w8", "cgnn_aggregate_plan_bytes", "cgnn_aggregate_plan_build", "cgnn_aggregate_planned",
+    "cgnn_edge_stream_run", "cgnn_edge_stream_w8_supported", "cgnn_edge_stream_image_build_w8", "cgnn_edge_stream_run_w8", "cgnn_aggregate_plan_bytes", "cgnn_aggregate_plan_build", "cgnn_aggregate_planned", "cgnn_aggregate_planned_rows",
 )
 ROWS, TILED32 = 0, 1
 
@@ -101,6 +101,7 @@ def load() -> C.CDLL:
     lib.cgnn_aggregate_plan_bytes.argtypes = [i64, i32]
     lib.cgnn_aggregate_plan_build.argtypes = [vp, i64, i32, vp, vp]
     lib.cgnn_aggregate_planned.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp]
+    lib.cgnn_aggregate_planned_rows.argtypes = [vp, i64, vp, vp, i64, i32, i32, vp, vp]
     lib.cgnn_node_block.argtypes = [C.POINTER(Mlp), C.POINTER(Linear), C.POINTER(Linear), vp, vp, i64, vp, i32, i32,
                                     C.POINTER(Linear), C.POINTER(Linear), i32, vp, vp, i32, vp]
     lib.cgnn_knn_workspace_bytes.restype = sz

@@ -15,10 +15,16 @@
 // A block with more than 352 distinct senders (strongly clustered particles, random graphs) gathers straight from memory
 // like the plain kernel.
 #include <type_traits>
+#include <utility>
 
 #include "cgnn_common.hpp"
 
 namespace cgnn {
+
+template <class F, int... I>
+__device__ __forceinline__ void ap_static_for(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
 
 // receivers per block: 64 for the unrolled k = 8 / 16 kernels (two receivers per thread), 32 for the runtime-k kernel
 // (one per thread; up to k = 32 a block's distinct senders then still fit the staging area)
@@ -29,6 +35,9 @@ __host__ __device__ inline int ap_block_rows(int k) { return (k == 8 || k == 16)
 #define CGNN_AP_HASH 4096              // open-addressing table (>= 2 x the most keys a block can hold ... see build)
 #define CGNN_AP_THREADS 256
 #define CGNN_AP_MAX_K 32               // 64 x 32 = 2048 references per block
+// buffer offset of "no row" in the branch-free loads / stores: past the end of any table the path is used for (< 4 GiB - 2 KiB)
+// and, with the largest slice offset (7 x 128 bytes) added, still below 2^32 -- the range check is made on the 32-bit sum
+#define CGNN_AP_NO_ROW 0xfffffbf0u
 
 // plan blob: [count: nblocks x int32, padded to 256 B][unique: nblocks x 512 x int32][local: num_edges x uint16]
 struct PlanView {
@@ -117,8 +126,10 @@ __global__ __launch_bounds__(CGNN_AP_THREADS) void aggregate_plan_kernel(const i
 // buffer loads without a branch (a lane without a row gets an offset past the end: no memory access, zeros) in straight-line
 // code, so that hipcc's own waits are exact counts -- with `if (row) load` in a runtime loop it waited vmcnt(0) before
 // nearly every use and the "two slices in flight" were one.
+// (three waves per SIMD asked of the branch-free k = 8 / 16 forms: 168 registers, three workgroups per CU -- they compile to
+// 168-170 without the hint)
 template <int K, int SL>   // K = 8, 16: unrolled balanced tree (cgnn_aggregate's order); 0: runtime k, left to right
-__global__ __launch_bounds__(CGNN_AP_THREADS) void aggregate_planned_kernel(const float* __restrict__ table,
+__global__ __launch_bounds__(CGNN_AP_THREADS, (K != 0 && SL != 0) ? 3 : 1) void aggregate_planned_kernel(const float* __restrict__ table,
                                                                             const int32_t* __restrict__ gather, PlanView plan,
                                                                             int krt, int64_t num_nodes, int width,
                                                                             float* __restrict__ out) {
@@ -192,15 +203,18 @@ __global__ __launch_bounds__(CGNN_AP_THREADS) void aggregate_planned_kernel(cons
 #pragma unroll
     for (int i = 0; i < PASSES; ++i) mine[i] = r_lo + 32 * i < U ? uq[r_lo + 32 * i] : -1;
     const float* const tcol = table + chunk * 4;
-    // two slices in flight: slice s + 2 is requested when slice s has been copied to LDS
-    f32x4 pre[2][PASSES];
+    // NPRE slices in flight: slice s + NPRE is requested when slice s has been copied to LDS (three measured slower: 232
+    // registers, two workgroups per CU)
+    constexpr int NPRE = 2;
+    f32x4 pre[NPRE][PASSES];
     unsigned off[PASSES];      // SL: byte offset of the lane's piece of row mine[i] (past the end: no row)
     (void)off;
     auto fetch = [&](f32x4 (&dstp)[PASSES], int sl) __attribute__((always_inline)) {
         if constexpr (SL != 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
+            // (every row offset below "no row" is in range: the table may be longer than the receivers' part of it)
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(table), 0, (int)((unsigned)num_nodes * (unsigned)width * 4u), 0x00020000);
+                const_cast<float*>(table), 0, (int)CGNN_AP_NO_ROW, 0x00020000);
 #pragma unroll
             for (int i = 0; i < PASSES; ++i)
                 dstp[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off[i], sl * 128, 0));
@@ -214,10 +228,10 @@ __global__ __launch_bounds__(CGNN_AP_THREADS) void aggregate_planned_kernel(cons
     if constexpr (SL != 0) {
 #pragma unroll
         for (int i = 0; i < PASSES; ++i)
-            off[i] = mine[i] >= 0 ? (unsigned)mine[i] * (unsigned)width * 4u + (unsigned)chunk * 16u : 0xfffffff0u;
+            off[i] = mine[i] >= 0 ? (unsigned)mine[i] * (unsigned)width * 4u + (unsigned)chunk * 16u : CGNN_AP_NO_ROW;
     }
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < NPRE; ++p)
         if (p < slices) fetch(pre[p], p);
     auto one_slice = [&](int s, auto parity) __attribute__((always_inline)) {
         constexpr int P = decltype(parity)::value;
@@ -225,7 +239,7 @@ __global__ __launch_bounds__(CGNN_AP_THREADS) void aggregate_planned_kernel(cons
         for (int i = 0; i < PASSES; ++i)
             if (SL != 0 || mine[i] >= 0) stage[(r_lo + 32 * i) * CGNN_AP_ROW_F4 + chunk] = pre[P][i];      // (SL: zeros for "no row")
         __syncthreads();
-        if (s + 2 < slices) fetch(pre[P], s + 2);
+        if (s + NPRE < slices) fetch(pre[P], s + NPRE);
 #pragma unroll
         for (int half = 0; half < HALVES; ++half) {
             const int64_t row = row0 + r_lo + 32 * half;
@@ -242,18 +256,32 @@ __global__ __launch_bounds__(CGNN_AP_THREADS) void aggregate_planned_kernel(cons
                 for (int j = 0; j < KR; ++j)
                     if (j < k) acc += stage[(int)li[half][j] * CGNN_AP_ROW_F4 + chunk];
             }
-            if (row < num_nodes)
+            if constexpr (SL != 0 && K != 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                // (no branch either: a row past the end gets an offset past the end of `out`, the store is dropped; with it
+                // the k = 16 kernel needs 168 registers instead of 204: three workgroups per CU.  The runtime-k kernel
+                // measured 2 % slower this way and keeps the predicated store)
+                const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    out, 0, (int)((unsigned)num_nodes * (unsigned)width * 4u), 0x00020000);
+                const unsigned ooff = row < num_nodes ? (unsigned)row * (unsigned)width * 4u + (unsigned)chunk * 16u : CGNN_AP_NO_ROW;
+                // The slice offset travels in the VECTOR offset, the scalar offset stays the constant 0.  With a register in
+                // the scalar-offset field hipcc assumes that a 16-byte buffer store needs no wait state before a vector
+                // instruction overwrites its data registers (GCNHazardRecognizer: "this hazard only exists if the
+                // instruction is not using a register in the soffset field") -- on gfx950 it does: the next slice's
+                // v_pk_add_f32 into the same registers, issued right behind the store, changed element 1 of the stored
+                // vector in lanes 12-15 of every 16 (seen as wrong sums in odd rows; scripts/dev/dbg_agg.py).
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), orsrc, (int)(ooff + (unsigned)s * 128u), 0, 2 /* nt */);
+#endif
+            } else if (row < num_nodes) {
                 __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(out + row * width + s * 32 + chunk * 4));
+            }
         }
         __syncthreads();                            // everybody is done reading this slice
     };
     if constexpr (SL != 0) {
-        static_assert(SL % 2 == 0, "unrolled slice loop: an even count");
-#pragma unroll
-        for (int s = 0; s < SL; s += 2) {
-            one_slice(s, std::integral_constant<int, 0>{});
-            one_slice(s + 1, std::integral_constant<int, 1>{});
-        }
+        ap_static_for([&](auto sc) __attribute__((always_inline)) {
+            one_slice(decltype(sc)::value, std::integral_constant<int, decltype(sc)::value % NPRE>{});
+        }, std::make_integer_sequence<int, SL>{});
     } else {
         for (int s = 0; s < slices; s += 2) {
             one_slice(s, std::integral_constant<int, 0>{});
@@ -291,7 +319,12 @@ int cgnn_aggregate_plan_build(const int32_t* gather, int64_t num_nodes, int32_t 
 
 int cgnn_aggregate_planned(const float* table, const int32_t* gather, const void* plan, int64_t num_nodes, int32_t fixed_k,
                            int32_t width, float* out, void* stream) {
-    if (!table || !gather || !plan || !out || num_nodes < 0 || fixed_k <= 0 || width <= 0) {
+    return cgnn_aggregate_planned_rows(table, 0, gather, plan, num_nodes, fixed_k, width, out, stream);
+}
+
+int cgnn_aggregate_planned_rows(const float* table, int64_t table_rows, const int32_t* gather, const void* plan,
+                                int64_t num_nodes, int32_t fixed_k, int32_t width, float* out, void* stream) {
+    if (!table || !gather || !plan || !out || num_nodes < 0 || fixed_k <= 0 || width <= 0 || table_rows < 0) {
         set_error("cgnn_aggregate_planned: invalid argument");
         return CGNN_ERR_INVALID_ARG;
     }
@@ -305,8 +338,11 @@ int cgnn_aggregate_planned(const float* table, const int32_t* gather, const void
     const PlanView pv = plan_view(const_cast<void*>(plan), nblocks);
     const int lds = CGNN_AP_STAGE_ROWS * CGNN_AP_ROW_F4 * 16;
     hipStream_t st = (hipStream_t)stream;
-    // unrolled slice loop + branch-free buffer loads: latent 128 / 256 with the table below 4 GiB (32-bit row offsets)
-    const int sl = ((int64_t)num_nodes * width * 4 < ((int64_t)1 << 32) - 16 && (width == 128 || width == 256)) ? width / 32 : 0;
+    // unrolled slice loop + branch-free buffer loads / stores: latent 128 / 256 with table and output below 4 GiB (32-bit
+    // row offsets).  The table may hold more rows than there are receivers (ghost rows of a spatial shard): its row count
+    // must be known (cgnn_aggregate_planned_rows), else the general kernel runs
+    const int64_t most_rows = table_rows > num_nodes ? table_rows : num_nodes;
+    const int sl = (table_rows > 0 && most_rows * width * 4 <= (int64_t)CGNN_AP_NO_ROW && (width == 128 || width == 256)) ? width / 32 : 0;
 #define CGNN_AP_GO(Kk)                                                                                              \
     if (sl == 4) CGNN_AP_GO2(Kk, 4) else if (sl == 8) CGNN_AP_GO2(Kk, 8) else CGNN_AP_GO2(Kk, 0)
 #define CGNN_AP_GO2(Kk, SLl)                                                                                        \

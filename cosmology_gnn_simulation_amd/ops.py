@@ -491,9 +491,10 @@ def aggregate(table, gather: Optional[torch.Tensor], dst: Optional[torch.Tensor]
             out = torch.empty((num_nodes, table.shape[1]), dtype=torch.float32, device=table.device)
         _same_device(table, gather, plan.blob, out)
         with _timed("aggregate", table.device):
-            check(_lib.load().cgnn_aggregate_planned(table.data_ptr(), gather.data_ptr(), plan.blob.data_ptr(),
-                                                     num_nodes, fixed_k, table.shape[1], out.data_ptr(),
-                                                     stream_ptr(table.device)), "cgnn_aggregate_planned")
+            check(_lib.load().cgnn_aggregate_planned_rows(table.data_ptr(), table.shape[0], gather.data_ptr(),
+                                                          plan.blob.data_ptr(), num_nodes, fixed_k, table.shape[1],
+                                                          out.data_ptr(), stream_ptr(table.device)),
+                  "cgnn_aggregate_planned")
         return out
     if isinstance(table, TiledRows):
         tb, layout, width, dev, nrows = table.buf, _lib.TILED32, table.width, table.device, table.n

@@ -199,6 +199,11 @@ size_t cgnn_aggregate_plan_bytes(int64_t num_nodes, int32_t fixed_k);
 int cgnn_aggregate_plan_build(const int32_t* gather, int64_t num_nodes, int32_t fixed_k, void* plan, void* stream);
 int cgnn_aggregate_planned(const float* table, const int32_t* gather, const void* plan, int64_t num_nodes,
                            int32_t fixed_k, int32_t width, float* out, void* stream);
+/* The same with the table's row count (>= 1 + the largest sender id; a spatial shard's table holds ghost rows behind the
+ * receivers'): known, and with table and output below 4 GiB at width 128 / 256, the kernel addresses rows by 32-bit buffer
+ * offsets without branches (faster, same bits). */
+int cgnn_aggregate_planned_rows(const float* table, int64_t table_rows, const int32_t* gather, const void* plan,
+                                int64_t num_nodes, int32_t fixed_k, int32_t width, float* out, void* stream);
 
 /* ---- K8+K9: fused node update --------------------------------------------------
  *   u = LayerNorm(MLP(cat[x, agg]))                          graph_network.py:94-96

@@ -69,7 +69,42 @@ def scan(path):
     return findings
 
 
+# ---- second hazard: wide buffer store with a REGISTER in the scalar-offset field, data registers overwritten right behind it
+# hipcc pads "VMEM store of more than 8 bytes followed by a VALU write of its data registers" with a wait state only when
+# the store's soffset field is NOT a register (GCNHazardRecognizer::createsVALUHazard).  On gfx950 the hazard is there with a
+# register too: a v_pk_add_f32 into the data registers issued right behind `buffer_store_dwordx4 v[12:15], v135, s[8:11], s19
+# offen` changed what was stored (round 3, planned aggregation: element 1 of lanes 12-15 of every 16).
+WIDE_STORE = re.compile(r"^\s*buffer_store_dwordx([34])\s+v\[(\d+):(\d+)\],\s*\S+,\s*s\[\d+:\d+\],\s*(\S+)")
+VDST = re.compile(r"^\s*v_\w+\s+v(?:\[(\d+):(\d+)\]|(\d+))")
+
+
+def scan_store_hazard(path):
+    findings = []
+    kernel = "?"
+    pending = None                   # (line no, text, data registers) of a store still within one wait state
+    for no, line in enumerate(open(path), 1):
+        s = line.strip()
+        if s.endswith(":") and not s.startswith("."):
+            kernel = s[:-1]
+            pending = None
+            continue
+        if not s or s.startswith(";") or s.startswith(".") or s.endswith(":"):
+            continue
+        if pending is not None:
+            m = VDST.match(s)
+            if m and not s.startswith("v_mfma"):
+                dst = set(range(int(m.group(1)), int(m.group(2)) + 1)) if m.group(3) is None else {int(m.group(3))}
+                if dst & pending[2]:
+                    findings.append(f"{path}:{no}: {kernel}: '{s}' overwrites the data of '{pending[1]}' (line {pending[0]}) "
+                                    f"without a wait state (soffset is a register: hipcc does not pad)")
+            pending = None
+        m = WIDE_STORE.match(s)
+        if m and m.group(4).rstrip(",").startswith("s"):
+            pending = (no, s, set(range(int(m.group(2)), int(m.group(3)) + 1)))
+    return findings
+
+
 if __name__ == "__main__":
-    bad = [f for p in sys.argv[1:] for f in scan(p)]
-    print("\n".join(bad) if bad else "no VALU-SGPR -> asm VMEM hazards")
+    bad = [f for p in sys.argv[1:] for f in scan(p) + scan_store_hazard(p)]
+    print("\n".join(bad) if bad else "no VALU-SGPR -> asm VMEM hazards, no unpadded wide buffer stores")
     sys.exit(1 if bad else 0)

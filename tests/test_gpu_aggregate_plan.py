@@ -113,3 +113,24 @@ def test_model_forward_is_unchanged_by_the_plan():
         finally:
             ops.AggregatePlan.MIN_NODES = saved
     assert torch.equal(a["acceleration"], b["acceleration"]) and torch.equal(a["temp_rate"], b["temp_rate"])
+
+
+def test_table_longer_than_the_receivers_part():
+    """A spatial shard's table holds ghost rows behind the owned (receiver) rows and its senders point into them: the
+    branch-free kernel addresses rows by buffer offsets and must not take the receiver count for the table's length
+    (round 3: ghost senders read as zeros until cgnn_aggregate_planned_rows was given the table's row count)."""
+    n, ghosts, k, width = 9000, 700, 16, 128
+    gen = torch.Generator().manual_seed(11)
+    src = _knn_senders(n, k, 5)
+    # redirect a tenth of the references to ghost rows
+    pick = torch.rand(n * k, generator=gen).to(DEV) < 0.1
+    ghost_ids = torch.randint(n, n + ghosts, (n * k,), generator=gen).int().to(DEV)
+    src = torch.where(pick, ghost_ids, src).contiguous()
+    table = torch.randn(n + ghosts, width, device=DEV)
+    plain = ops.aggregate(table, src, None, n, k)
+    plan = ops.AggregatePlan(src, n, k)
+    got = ops.aggregate(table, src, None, n, k, plan=plan)
+    assert got.shape == (n, width) and torch.equal(got, plain)
+    dst = torch.arange(n).repeat_interleave(k)
+    want = torch.zeros(n, width).index_add_(0, dst, table.cpu()[src.cpu().long()])
+    assert float((got.cpu() - want).abs().max()) <= 1e-5 * float(want.abs().max())

@@ -188,7 +188,10 @@ def test_kernels_with_hand_issued_loads_use_no_scratch_and_pad_their_own_hazards
             ("edge_stream.hip", (), ""), ("node_block_n16.hip", (), ""), ("edge_block.hip", (), "n16_kernel"),
             # the bench's edge stream (two waves per SIMD): its encoder form (ENC = true: "ELb1E") is the one that runs in the
             # model; a spill there reloads behind vmcnt(0) and drains the ring's prefetches
-            ("edge_stream32w.hip", ("-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"), "ELb1E")]
+            ("edge_stream32w.hip", ("-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"), "ELb1E"),
+            # planned aggregation: branch-free buffer loads / stores (round 3).  Its 16-byte buffer stores are what the second
+            # scan below is about
+            ("aggregate_plan.hip", (), "planned_kernelILi16E")]
     with concurrent.futures.ThreadPoolExecutor(4) as pool:
         for (name, text, path), (_, _, must) in zip(pool.map(lambda j: listing(*j[:2]), jobs), jobs):
             sizes = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", text)]
@@ -199,6 +202,28 @@ def test_kernels_with_hand_issued_loads_use_no_scratch_and_pad_their_own_hazards
             assert not bad, (name, bad)
             assert any(must in k for k in kernels), name
             assert scan_asm_hazards.scan(path) == [], name
+            # a 16-byte buffer store with a REGISTER in its scalar-offset field, data registers overwritten by the very next
+            # vector instruction: hipcc pads that only for a constant soffset, gfx950 needs the wait state either way (wrong
+            # sums in round 3's first branch-free aggregation kernel; scripts/dev/scan_asm_hazards.py)
+            assert scan_asm_hazards.scan_store_hazard(path) == [], name
+
+
+def test_store_hazard_scanner_sees_an_unpadded_wide_buffer_store(tmp_path):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts", "dev"))
+    try:
+        import scan_asm_hazards
+    finally:
+        sys.path.pop(0)
+    body = ("k:\n\tbuffer_store_dwordx4 v[12:15], v135, s[8:11], %s offen\n%s\tv_pk_add_f32 v[12:13], v[148:149], v[152:153]\n"
+            "\ts_endpgm\n")
+    cases = {"reg": ("s19", ""), "const": ("0", ""), "padded": ("s19", "\ts_nop 0\n"), "other": ("s19", "\tv_mov_b32_e32 v1, v2\n")}
+    found = {}
+    for name, (soff, between) in cases.items():
+        f = tmp_path / (name + ".s")
+        f.write_text(body % (soff, between))
+        found[name] = len(scan_asm_hazards.scan_store_hazard(str(f)))
+    assert found == {"reg": 1, "const": 0, "padded": 0, "other": 0}
 
 
 def test_asm_hazard_scanner_sees_a_short_gap(tmp_path):
