@@ -259,7 +259,9 @@ __global__ __launch_bounds__(CGNN_BLOCK) void weight_grad_kernel(const float* __
 // out[c] += sum_r a[r,c] (* b[r,c]): lanes take 4 columns x 1 row each (16-byte loads when aligned), the row lanes
 // of a workgroup meet in LDS, one atomic per column per workgroup.
 #define CGNN_COLDOT_ROWS 512
-template <bool BOTH>      // BOTH: out2[c] += sum_r a[r,c] as well (a is read once for the two sums)
+// PART: instead of the atomics every workgroup writes its sums to part[blockIdx.x][0 / 1][width] (col_dot_reduce_kernel adds
+// them in a fixed order: the result has the same bits on every run).
+template <bool BOTH, bool PART = false>      // BOTH: out2[c] += sum_r a[r,c] as well (a is read once for the two sums)
 __global__ __launch_bounds__(CGNN_BLOCK) void col_dot_kernel(const float* __restrict__ a, int ld_a,
                                                              const float* __restrict__ b, int ld_b, int64_t n,
                                                              int width, float* __restrict__ out,
@@ -320,10 +322,39 @@ __global__ __launch_bounds__(CGNN_BLOCK) void col_dot_kernel(const float* __rest
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (c + j < width) {
-                    atomicAdd(out + c + j, red[threadIdx.x][j]);
-                    if (BOTH) atomicAdd(out2 + c + j, red[threadIdx.x][4 + j]);
+                    if (PART) {      // out = the partial-sum workspace
+                        float* const mine = out + (int64_t)blockIdx.x * (BOTH ? 2 : 1) * width;
+                        mine[c + j] = red[threadIdx.x][j];
+                        if (BOTH) mine[width + c + j] = red[threadIdx.x][4 + j];
+                    } else {
+                        atomicAdd(out + c + j, red[threadIdx.x][j]);
+                        if (BOTH) atomicAdd(out2 + c + j, red[threadIdx.x][4 + j]);
+                    }
                 }
         __syncthreads();
+    }
+}
+
+// out[c] += the partial sums of column c over all workgroups, in a fixed order: four row lanes take every fourth partial
+// each, left to right, and meet left to right.  One workgroup per 64 columns.
+__global__ __launch_bounds__(CGNN_BLOCK) void col_dot_reduce_kernel(const float* __restrict__ part, int64_t nblocks, int nsums,
+                                                                   int width, float* __restrict__ out,
+                                                                   float* __restrict__ out2) {
+    __shared__ float red[CGNN_BLOCK][2];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < width)
+        for (int64_t blk = rl; blk < nblocks; blk += CGNN_BLOCK / 64) {
+            s0 += part[blk * nsums * width + c];
+            if (nsums == 2) s1 += part[blk * nsums * width + width + c];
+        }
+    red[threadIdx.x][0] = s0;
+    red[threadIdx.x][1] = s1;
+    __syncthreads();
+    if (rl == 0 && c < width) {
+        const int t = threadIdx.x;
+        out[c] += ((red[t][0] + red[t + 64][0]) + red[t + 128][0]) + red[t + 192][0];
+        if (nsums == 2) out2[c] += ((red[t][1] + red[t + 64][1]) + red[t + 128][1]) + red[t + 192][1];
     }
 }
 
@@ -472,6 +503,37 @@ int cgnn_col_dot(const float* a, int32_t ld_a, const float* b, int32_t ld_b, int
     col_dot_kernel<false><<<(unsigned)((n + CGNN_COLDOT_ROWS - 1) / CGNN_COLDOT_ROWS), CGNN_BLOCK, 0,
                             (hipStream_t)stream>>>(a, ld_a, b, ld_b, n, width, out, nullptr);
     return check_hip(hipGetLastError(), "cgnn_col_dot launch");
+}
+
+size_t cgnn_col_dot_workspace_bytes(int64_t n, int32_t width) {
+    if (n <= 0 || width <= 0) return 0;
+    return (size_t)((n + CGNN_COLDOT_ROWS - 1) / CGNN_COLDOT_ROWS) * 2 * (size_t)width * sizeof(float);
+}
+
+// The same sums with the same bits on every run: per-workgroup partial sums in `workspace`, added in a fixed order by a
+// second kernel (cgnn_col_dot / cgnn_col_dot2 meet in float atomics).  out_a may be NULL (then b may be NULL as well).
+int cgnn_col_dot_ordered(const float* a, int32_t ld_a, const float* b, int32_t ld_b, int64_t n, int32_t width, float* out_ab,
+                         float* out_a, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!a || !out_ab || width <= 0 || n < 0 || ld_a < width || (b && ld_b < width) || (out_a && !b) || !workspace) {
+        set_error("cgnn_col_dot_ordered: invalid argument");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if (workspace_bytes < cgnn_col_dot_workspace_bytes(n, width)) {
+        set_error("cgnn_col_dot_ordered: workspace has %zu bytes, needs %zu", workspace_bytes,
+                  cgnn_col_dot_workspace_bytes(n, width));
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if (n == 0) return CGNN_OK;
+    static_assert(CGNN_BLOCK == 256, "col_dot_reduce_kernel adds four row lanes");
+    const unsigned nblocks = (unsigned)((n + CGNN_COLDOT_ROWS - 1) / CGNN_COLDOT_ROWS);
+    float* part = reinterpret_cast<float*>(workspace);
+    hipStream_t st = (hipStream_t)stream;
+    if (out_a)
+        col_dot_kernel<true, true><<<nblocks, CGNN_BLOCK, 0, st>>>(a, ld_a, b, ld_b, n, width, part, nullptr);
+    else
+        col_dot_kernel<false, true><<<nblocks, CGNN_BLOCK, 0, st>>>(a, ld_a, b, ld_b, n, width, part, nullptr);
+    col_dot_reduce_kernel<<<(unsigned)((width + 63) / 64), CGNN_BLOCK, 0, st>>>(part, nblocks, out_a ? 2 : 1, width, out_ab, out_a);
+    return check_hip(hipGetLastError(), "cgnn_col_dot_ordered launch");
 }
 
 int cgnn_col_dot2(const float* a, int32_t ld_a, const float* b, int32_t ld_b, int64_t n, int32_t width, float* out_ab,

@@ -769,28 +769,45 @@ def aggregate_csr(table: torch.Tensor, csr: SenderCsr, out: Optional[torch.Tenso
     return out
 
 
+_COLDOT_WORKSPACE = {}
+
+
+def _col_dot_workspace(a: torch.Tensor, n: int, width: int) -> torch.Tensor:
+    """Partial-sum scratch of the fixed-order column sums: one per (device, stream), grown on demand."""
+    need = _lib.load().cgnn_col_dot_workspace_bytes(n, width)
+    key = (a.device.type, a.device.index, stream_ptr(a.device))     # per stream: calls on one stream are ordered
+    ws = _COLDOT_WORKSPACE.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _COLDOT_WORKSPACE[key] = torch.empty(max(need, 1), dtype=torch.uint8, device=a.device)
+    return ws
+
+
 def col_dot(a: torch.Tensor, ld_a: int, b: Optional[torch.Tensor], ld_b: int, n: int, width: int,
             out: torch.Tensor) -> torch.Tensor:
-    """``out[c] += sum_r a[r, c] * (b[r, c] if b is not None else 1)``."""
+    """``out[c] += sum_r a[r, c] * (b[r, c] if b is not None else 1)``, summed in a fixed order (the same bits on
+    every run: ``cgnn_col_dot_ordered``)."""
     require_device(a, "a")
     if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() < width:
         raise CgnnError("col_dot: out must be contiguous float32 [width]")
+    ws = _col_dot_workspace(a, n, width)
     with _timed("col_dot", a.device):
-        check(_lib.load().cgnn_col_dot(a.data_ptr(), ld_a, ptr(b), ld_b, n, width, out.data_ptr(),
-                                       stream_ptr(a.device)), "cgnn_col_dot")
+        check(_lib.load().cgnn_col_dot_ordered(a.data_ptr(), ld_a, ptr(b), ld_b, n, width, out.data_ptr(), None,
+                                               ws.data_ptr(), ws.numel(), stream_ptr(a.device)), "cgnn_col_dot_ordered")
     return out
 
 
 def col_dot2(a: torch.Tensor, ld_a: int, b: torch.Tensor, ld_b: int, n: int, width: int, out_ab: torch.Tensor,
              out_a: torch.Tensor):
     """``out_ab[c] += sum_r a[r, c] * b[r, c]`` and ``out_a[c] += sum_r a[r, c]`` in one pass over ``a`` (LayerNorm's
-    ``dgamma`` and ``dbeta`` from ``dy`` and ``zhat``)."""
+    ``dgamma`` and ``dbeta`` from ``dy`` and ``zhat``), both in a fixed order (reproducible)."""
     require_device(a, "a")
     require_device(b, "b")
     for t in (out_ab, out_a):
         if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() < width:
             raise CgnnError("col_dot2: outputs must be contiguous float32 [width]")
+    ws = _col_dot_workspace(a, n, width)
     with _timed("col_dot", a.device):
-        check(_lib.load().cgnn_col_dot2(a.data_ptr(), ld_a, b.data_ptr(), ld_b, n, width, out_ab.data_ptr(),
-                                        out_a.data_ptr(), stream_ptr(a.device)), "cgnn_col_dot2")
+        check(_lib.load().cgnn_col_dot_ordered(a.data_ptr(), ld_a, b.data_ptr(), ld_b, n, width, out_ab.data_ptr(),
+                                               out_a.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr(a.device)),
+              "cgnn_col_dot_ordered")
     return out_ab, out_a

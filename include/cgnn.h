@@ -341,6 +341,13 @@ int cgnn_col_dot(const float* a, int32_t ld_a, const float* b, int32_t ld_b, int
 int cgnn_col_dot2(const float* a, int32_t ld_a, const float* b, int32_t ld_b, int64_t n, int32_t width, float* out_ab,
                   float* out_a, void* stream);
 
+/* The same sums reproducibly: per-workgroup partial sums in `workspace` (cgnn_col_dot_workspace_bytes(n, width) bytes of
+ * device memory, contents irrelevant), added in a fixed order by a second kernel -- the same bits on every run (the two
+ * entries above meet in float atomics).  out_a NULL: out_ab only (b may then be NULL: plain column sums). */
+size_t cgnn_col_dot_workspace_bytes(int64_t n, int32_t width);
+int cgnn_col_dot_ordered(const float* a, int32_t ld_a, const float* b, int32_t ld_b, int64_t n, int32_t width, float* out_ab,
+                         float* out_a, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- transpose of the aggregation (backward of graph_network.py:92 `propagate`) --------------------------------
  * cgnn_csr_build groups an edge list by `key`: row_ptr[r]..row_ptr[r+1] delimit, in col[], the `val` (or, when val
  * is NULL, the edge index) of every edge whose key is r, in ascending order (deterministic).  With key = senders and

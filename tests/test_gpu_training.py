@@ -410,3 +410,37 @@ def test_training_with_the_edge_stream_switched_on_changes_no_output_and_no_grad
     with torch.no_grad():
         ref = model.forward_with_latents(g)["edge_latent"]
     assert bool(torch.isfinite(ref).all())
+
+
+@pytest.mark.parametrize("n,width", [(70_001, 128), (300_000, 256), (513, 3), (1, 64)])
+def test_column_sums_have_the_same_bits_on_every_run(n, width):
+    """LayerNorm's dgamma / dbeta and the bias gradients are column sums over all particles: cgnn_col_dot_ordered adds the
+    per-workgroup partial sums in a fixed order (the atomic forms cgnn_col_dot / cgnn_col_dot2 do not), so a training
+    step's affine and bias gradients are reproducible.  Also its error behaviour at the C ABI."""
+    gen = torch.Generator().manual_seed(n + width)
+    a = torch.randn(n, width, generator=gen).to(DEV)
+    b = torch.randn(n, width, generator=gen).to(DEV)
+    runs = []
+    for _ in range(4):
+        o_ab, o_a = torch.zeros(width, device=DEV), torch.zeros(width, device=DEV)
+        ops.col_dot2(a, width, b, width, n, width, o_ab, o_a)
+        o_s = torch.zeros(width, device=DEV)
+        ops.col_dot(a, width, None, 0, n, width, o_s)
+        runs.append((o_ab.clone(), o_a.clone(), o_s.clone()))
+        # (other work in between: the order must not depend on what ran before)
+        torch.randn(1 << 20, device=DEV).sum()
+    for r in runs[1:]:
+        assert all(torch.equal(x, y) for x, y in zip(r, runs[0]))
+    assert torch.equal(runs[0][1], runs[0][2])                                  # the same column sums through either entry
+    assert _close(runs[0][0], (a.double() * b.double()).sum(0).float(), 1e-5)
+    assert _close(runs[0][1], a.double().sum(0).float(), 1e-5)
+    # outputs are accumulated into, like the atomic forms
+    o = torch.ones(width, device=DEV)
+    ops.col_dot(a, width, None, 0, n, width, o)
+    assert _close(o - 1, a.double().sum(0).float(), 1e-4)
+    lib = _lib.load()
+    ws = torch.empty(16, dtype=torch.uint8, device=DEV)                         # too small
+    rc = lib.cgnn_col_dot_ordered(a.data_ptr(), width, None, 0, n, width, o.data_ptr(), None, ws.data_ptr(), ws.numel(), None)
+    assert (rc != 0) == (lib.cgnn_col_dot_workspace_bytes(n, width) > 16)
+    rc = lib.cgnn_col_dot_ordered(a.data_ptr(), width, None, 0, n, width, o.data_ptr(), o.data_ptr(), ws.data_ptr(), ws.numel(), None)
+    assert rc == -1 and b"cgnn_col_dot_ordered" in lib.cgnn_last_error()      # out_a without b
