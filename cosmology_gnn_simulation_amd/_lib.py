@@ -35,7 +35,7 @@ EXPORTS = (
     "cgnn_knn_workspace_bytes", "cgnn_knn_periodic", "cgnn_knn_sorted_order", "cgnn_segment_colsum",
     "cgnn_gather_rows", "cgnn_scatter_rows", "cgnn_tiled_rows", "cgnn_relayout", "cgnn_window_features",
     "cgnn_mlp_backward", "cgnn_weight_grad", "cgnn_weight_grad_x3_workspace_bytes", "cgnn_weight_grad_x3",
-    "cgnn_col_dot", "cgnn_col_dot2", "cgnn_col_dot_workspace_bytes", "cgnn_col_dot_ordered", "cgnn_csr_workspace_bytes", "cgnn_csr_build",
+    "cgnn_col_dot", "cgnn_col_dot2", "cgnn_col_dot_workspace_bytes", "cgnn_col_dot_ordered", "cgnn_weight_grad_workspace_bytes", "cgnn_weight_grad_ordered", "cgnn_csr_workspace_bytes", "cgnn_csr_build",
     "cgnn_aggregate_csr", "cgnn_aggregate_csr_add", "cgnn_edge_stream", "cgnn_edge_stream_image_bytes", "cgnn_edge_stream_image_build",
     "cgnn_edge_stream_run", "cgnn_edge_stream_w8_supported", "cgnn_edge_stream_image_build_w8", "cgnn_edge_stream_run_w8", "cgnn_aggregate_plan_bytes", "cgnn_aggregate_plan_build", "cgnn_aggregate_planned", "cgnn_aggregate_planned_rows",
 )
@@ -126,6 +126,9 @@ def load() -> C.CDLL:
     lib.cgnn_col_dot.argtypes = [vp, i32, vp, i32, i64, i32, vp, vp]
     lib.cgnn_col_dot2.argtypes = [vp, i32, vp, i32, i64, i32, vp, vp, vp]
     lib.cgnn_col_dot_workspace_bytes.restype = sz
+    lib.cgnn_weight_grad_workspace_bytes.restype = sz
+    lib.cgnn_weight_grad_workspace_bytes.argtypes = [i64, i32, i32]
+    lib.cgnn_weight_grad_ordered.argtypes = [vp, i32, i32, vp, i32, i32, i64, vp, i32, i32, vp, vp, sz, vp]
     lib.cgnn_col_dot_workspace_bytes.argtypes = [i64, i32]
     lib.cgnn_col_dot_ordered.argtypes = [vp, i32, vp, i32, i64, i32, vp, vp, vp, sz, vp]
     missing = [name for name in EXPORTS if not hasattr(lib, name)]

@@ -198,20 +198,23 @@ __global__ __launch_bounds__(CGNN_BLOCK) void mlp_backward_kernel(
 // dw[o, col0+i] += sum_r g[r,o] a[r,i] (and db[o] += sum_r g[r,o]): per workgroup one chunk of rows; each wave
 // owns one 32-wide slab of g's columns (an output tile) against G 32-wide slabs of a at once, so g is read once
 // per G input tiles and the column sums of g -- the bias gradient -- fall out of the A operands already loaded.
+// PART (cgnn_weight_grad_ordered): no atomics -- row chunk c writes its products to part_w[c][32 OT][32 IT] (dw's tile
+// grid, padded) and its column sums to part_b[c][32 OT]; weight_grad_reduce_kernel adds the chunks in a fixed order.
 #define CGNN_WGRAD_ROWS 1024
-template <int G>
+#define CGNN_WGRAD_MAX_CHUNKS 256      // ordered form: the workspace holds one dw per row chunk: see wgrad_ordered_shape
+template <int G, bool PART = false>
 __global__ __launch_bounds__(CGNN_BLOCK) void weight_grad_kernel(const float* __restrict__ g, int ld_g, int out_dim,
                                                                  const float* __restrict__ a, int ld_a, int in_dim,
                                                                  int64_t n, int it_groups, int n_items,
                                                                  float* __restrict__ dw, int ld_dw, int col0,
-                                                                 float* __restrict__ db) {
+                                                                 float* __restrict__ db, int64_t chunk_rows = CGNN_WGRAD_ROWS) {
     const int lane = threadIdx.x & 63, i = lane & 31, kk = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int item = blockIdx.y * CGNN_WAVES_PER_BLOCK + wave;
     if (item >= n_items) return;
     const int ot = item / it_groups, ig = item % it_groups;
-    const int64_t r0 = (int64_t)blockIdx.x * CGNN_WGRAD_ROWS;
-    const int64_t r1 = r0 + CGNN_WGRAD_ROWS < n ? r0 + CGNN_WGRAD_ROWS : n;
+    const int64_t r0 = (int64_t)blockIdx.x * chunk_rows;
+    const int64_t r1 = r0 + chunk_rows < n ? r0 + chunk_rows : n;
     const int oc = 32 * ot + i;
     const bool o_ok = oc < out_dim;
     bool i_ok[G];
@@ -248,11 +251,55 @@ __global__ __launch_bounds__(CGNN_BLOCK) void weight_grad_kernel(const float* __
 #pragma unroll
         for (int x = 0; x < 16; ++x) {
             const int o = 32 * ot + (x & 3) + 8 * (x >> 2) + 4 * kk;
-            if (o < out_dim && i_ok[q]) atomicAdd(dw + (int64_t)o * ld_dw + col0 + 32 * (ig * G + q) + i, acc[q][x]);
+            if (PART) {      // dw = part_w, ld_dw = 32 IT (padded in_dim), col0 = 32 OT (padded out_dim): every slot is written
+                if (32 * (ig * G + q) < ld_dw)
+                    dw[((int64_t)blockIdx.x * col0 + o) * ld_dw + 32 * (ig * G + q) + i] = acc[q][x];
+            } else if (o < out_dim && i_ok[q]) {
+                atomicAdd(dw + (int64_t)o * ld_dw + col0 + 32 * (ig * G + q) + i, acc[q][x]);
+            }
         }
     if (db != nullptr && ig == 0) {
         colsum += __shfl_xor(colsum, 32);
-        if (kk == 0 && o_ok) atomicAdd(db + oc, colsum);
+        if (PART) {
+            if (kk == 0) db[(int64_t)blockIdx.x * col0 + oc] = colsum;
+        } else if (kk == 0 && o_ok) {
+            atomicAdd(db + oc, colsum);
+        }
+    }
+}
+
+// dw[o, col0 + i] += sum over chunks of part_w[c][o][i], db[o] += sum of part_b[c][o], in a fixed order: a workgroup takes
+// 32 consecutive elements, eight lanes per element add every eighth chunk each (c = j, j + 8, ...), the eight meet left to
+// right.  (One thread per element walking all chunks left a 128 x 128 reduction with 64 workgroups: 18 ms per step.)
+__global__ __launch_bounds__(CGNN_BLOCK) void weight_grad_reduce_kernel(const float* __restrict__ part_w,
+                                                                       const float* __restrict__ part_b, int chunks, int po,
+                                                                       int pi, int out_dim, int in_dim, float* __restrict__ dw,
+                                                                       int ld_dw, int col0, float* __restrict__ db) {
+    __shared__ float red[8][33];
+    const int el = threadIdx.x & 31, j = threadIdx.x >> 5;
+    const int64_t n_w = (int64_t)po * pi;
+    const int64_t e = (int64_t)blockIdx.x * 32 + el;      // elements of dw first, then (padded) those of db
+    const bool is_w = e < n_w;
+    const int64_t eb = e - n_w;
+    const bool is_b = !is_w && db != nullptr && eb < po;
+    float sum = 0.f;
+    if (is_w) {
+        for (int c = j; c < chunks; c += 8) sum += part_w[(int64_t)c * n_w + e];
+    } else if (is_b) {
+        for (int c = j; c < chunks; c += 8) sum += part_b[(int64_t)c * po + eb];
+    }
+    red[j][el] = sum;
+    __syncthreads();
+    if (j == 0) {
+        float t = red[0][el];
+#pragma unroll
+        for (int x = 1; x < 8; ++x) t += red[x][el];
+        if (is_w) {
+            const int o = (int)(e / pi), i = (int)(e % pi);
+            if (o < out_dim && i < in_dim) dw[(int64_t)o * ld_dw + col0 + i] += t;
+        } else if (is_b && eb < out_dim) {
+            db[eb] += t;
+        }
     }
 }
 
@@ -491,6 +538,74 @@ int cgnn_weight_grad(const float* g, int32_t ld_g, int32_t out_dim, const float*
         weight_grad_kernel<1><<<grid, CGNN_BLOCK, 0, st>>>(g, ld_g, out_dim, a, ld_a, in_dim, n, it_groups, n_items, dw,
                                                            ld_dw, col0, db);
     return check_hip(hipGetLastError(), "cgnn_weight_grad launch");
+}
+
+static void wgrad_ordered_shape(int64_t n, int out_dim, int in_dim, int* chunks, int64_t* chunk_rows, int* po, int* pi) {
+    // as many row chunks as the atomic form (1024 rows each) while the partial products stay within 64 MiB, never fewer than
+    // CGNN_WGRAD_MAX_CHUNKS allows (256 x 256: 256 chunks of 256 KiB)
+    *po = (out_dim + 31) / 32 * 32;
+    *pi = (in_dim + 31) / 32 * 32;
+    int64_t c = (n + CGNN_WGRAD_ROWS - 1) / CGNN_WGRAD_ROWS;
+    int64_t cap = ((int64_t)64 << 20) / ((int64_t)*po * *pi * 4);
+    if (cap < CGNN_WGRAD_MAX_CHUNKS) cap = CGNN_WGRAD_MAX_CHUNKS;
+    if (c > cap) c = cap;
+    if (c < 1) c = 1;
+    int64_t rows = ((n + c - 1) / c + 7) / 8 * 8;
+    if (rows < 8) rows = 8;
+    *chunk_rows = rows;
+    *chunks = (int)((n + rows - 1) / rows);
+}
+
+size_t cgnn_weight_grad_workspace_bytes(int64_t n, int32_t out_dim, int32_t in_dim) {
+    if (n <= 0 || out_dim <= 0 || in_dim <= 0) return 0;
+    int chunks, po, pi;
+    int64_t rows;
+    wgrad_ordered_shape(n, out_dim, in_dim, &chunks, &rows, &po, &pi);
+    return (size_t)chunks * ((size_t)po * pi + po) * sizeof(float);
+}
+
+// cgnn_weight_grad with the same bits on every run: the row chunks' products go to `workspace` and are added in a fixed
+// order by a second kernel (any shape; the 128 x 128 Linears have cgnn_weight_grad_x3).
+int cgnn_weight_grad_ordered(const float* g, int32_t ld_g, int32_t out_dim, const float* a, int32_t ld_a, int32_t in_dim,
+                             int64_t n, float* dw, int32_t ld_dw, int32_t col0, float* db, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    if (!g || !a || !dw || !workspace || out_dim <= 0 || in_dim <= 0 || n < 0 || ld_g < out_dim || ld_a < in_dim ||
+        ld_dw < col0 + in_dim || col0 < 0) {
+        set_error("cgnn_weight_grad_ordered: invalid argument");
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if (workspace_bytes < cgnn_weight_grad_workspace_bytes(n, out_dim, in_dim)) {
+        set_error("cgnn_weight_grad_ordered: workspace has %zu bytes, needs %zu", workspace_bytes,
+                  cgnn_weight_grad_workspace_bytes(n, out_dim, in_dim));
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if (n == 0) return CGNN_OK;
+    int chunks, po, pi;
+    int64_t rows;
+    wgrad_ordered_shape(n, out_dim, in_dim, &chunks, &rows, &po, &pi);
+    float* part_w = reinterpret_cast<float*>(workspace);
+    float* part_b = part_w + (size_t)chunks * po * pi;
+    const int ot = po / 32, it = pi / 32;
+    const int G = it >= 4 ? 4 : (it >= 2 ? 2 : 1);
+    const int it_groups = (it + G - 1) / G;
+    const int n_items = ot * it_groups;
+    dim3 grid((unsigned)chunks, (unsigned)((n_items + CGNN_WAVES_PER_BLOCK - 1) / CGNN_WAVES_PER_BLOCK));
+    hipStream_t st = (hipStream_t)stream;
+    // (PART: dw = part_w, ld_dw = padded in_dim, col0 = padded out_dim, db = part_b: always written, read only if db != NULL)
+    if (G == 4)
+        weight_grad_kernel<4, true><<<grid, CGNN_BLOCK, 0, st>>>(g, ld_g, out_dim, a, ld_a, in_dim, n, it_groups, n_items,
+                                                                 part_w, pi, po, part_b, rows);
+    else if (G == 2)
+        weight_grad_kernel<2, true><<<grid, CGNN_BLOCK, 0, st>>>(g, ld_g, out_dim, a, ld_a, in_dim, n, it_groups, n_items,
+                                                                 part_w, pi, po, part_b, rows);
+    else
+        weight_grad_kernel<1, true><<<grid, CGNN_BLOCK, 0, st>>>(g, ld_g, out_dim, a, ld_a, in_dim, n, it_groups, n_items,
+                                                                 part_w, pi, po, part_b, rows);
+    const int64_t elems = (int64_t)po * pi + po;      // dw's, then db's
+    static_assert(CGNN_BLOCK == 256, "weight_grad_reduce_kernel: 32 elements x 8 lanes");
+    weight_grad_reduce_kernel<<<(unsigned)((elems + 31) / 32), CGNN_BLOCK, 0, st>>>(
+        part_w, part_b, chunks, po, pi, out_dim, in_dim, dw, ld_dw, col0, db);
+    return check_hip(hipGetLastError(), "cgnn_weight_grad_ordered launch");
 }
 
 int cgnn_col_dot(const float* a, int32_t ld_a, const float* b, int32_t ld_b, int64_t n, int32_t width, float* out,

@@ -723,10 +723,18 @@ def weight_grad(g: torch.Tensor, ld_g: int, out_dim: int, a: torch.Tensor, in_di
                                           col0, ptr(db), ws.data_ptr(), ws.numel(), stream_ptr(a.device)),
                   "cgnn_weight_grad_x3")
         return dw
+    # every other shape: exact f32 MFMA, the row chunks' products added in a fixed order (cgnn_weight_grad_ordered: the same
+    # bits on every run; cgnn_weight_grad itself meets in float atomics)
+    lib = _lib.load()
+    need = lib.cgnn_weight_grad_workspace_bytes(n, out_dim, in_dim)
+    key = (a.device.type, a.device.index, stream_ptr(a.device), "ordered")
+    ws = _WGRAD_WORKSPACE.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _WGRAD_WORKSPACE[key] = torch.empty(max(need, 1), dtype=torch.uint8, device=a.device)
     with _timed("weight_grad", a.device):
-        check(_lib.load().cgnn_weight_grad(g.data_ptr(), ld_g, out_dim, a.data_ptr(), a.stride(0), in_dim, n,
-                                           dw.data_ptr(), dw.stride(0), col0, ptr(db), stream_ptr(a.device)),
-              "cgnn_weight_grad")
+        check(lib.cgnn_weight_grad_ordered(g.data_ptr(), ld_g, out_dim, a.data_ptr(), a.stride(0), in_dim, n,
+                                           dw.data_ptr(), dw.stride(0), col0, ptr(db), ws.data_ptr(), ws.numel(),
+                                           stream_ptr(a.device)), "cgnn_weight_grad_ordered")
     return dw
 
 

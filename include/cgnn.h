@@ -322,6 +322,14 @@ int cgnn_mlp_backward(const cgnn_mlp* fwd, const cgnn_linear* fwd_part2, const c
 int cgnn_weight_grad(const float* g, int32_t ld_g, int32_t out_dim, const float* a, int32_t ld_a, int32_t in_dim,
                      int64_t n, float* dw, int32_t ld_dw, int32_t col0, float* db, void* stream);
 
+/* cgnn_weight_grad with the same bits on every run, any shape: the row chunks' products go to `workspace`
+ * (cgnn_weight_grad_workspace_bytes(n, out_dim, in_dim) bytes of device memory, contents irrelevant) and a second kernel adds
+ * them in a fixed order: dw[o, col0 + i] += ..., db[o] += ... (db may be NULL).  Exact f32 MFMA as cgnn_weight_grad. */
+size_t cgnn_weight_grad_workspace_bytes(int64_t n, int32_t out_dim, int32_t in_dim);
+int cgnn_weight_grad_ordered(const float* g, int32_t ld_g, int32_t out_dim, const float* a, int32_t ld_a, int32_t in_dim,
+                             int64_t n, float* dw, int32_t ld_dw, int32_t col0, float* db, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 /* The same reduction for a 128 x 128 Linear (out_dim == in_dim == 128) on the bf16 matrix cores, reproducible:
  * g and a are split into three bf16 terms in registers (six products, f32 accumulation: f32-level error, f32 exponent
  * range), every wave keeps the whole 128 x 128 product of its row range, writes it to `workspace`

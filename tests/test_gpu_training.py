@@ -444,3 +444,45 @@ def test_column_sums_have_the_same_bits_on_every_run(n, width):
     assert (rc != 0) == (lib.cgnn_col_dot_workspace_bytes(n, width) > 16)
     rc = lib.cgnn_col_dot_ordered(a.data_ptr(), width, None, 0, n, width, o.data_ptr(), o.data_ptr(), ws.data_ptr(), ws.numel(), None)
     assert rc == -1 and b"cgnn_col_dot_ordered" in lib.cgnn_last_error()      # out_a without b
+
+
+@pytest.mark.parametrize("n,out,fin,col0", [(70_001, 128, 17, 0), (300_000, 3, 128, 0), (2049, 1, 128, 0), (50_000, 64, 64, 64),
+                                            (40_000, 256, 256, 0), (9, 128, 21, 3)])
+def test_weight_gradients_of_every_shape_have_the_same_bits_on_every_run(n, out, fin, col0):
+    """cgnn_weight_grad_ordered (what ops.weight_grad runs for everything but the 128 x 128 Linears, which have
+    cgnn_weight_grad_x3): partial products per row chunk, added in a fixed order -- with the column sums above and the x3
+    kernel a whole training step's gradients are reproducible."""
+    gen = torch.Generator().manual_seed(n + out + fin)
+    ldg = (out + 31) // 32 * 32
+    g = torch.randn(n, ldg, generator=gen).to(DEV)
+    a = torch.randn(n, fin, generator=gen).to(DEV)
+    runs = []
+    for _ in range(3):
+        dw = torch.zeros(out, col0 + fin, device=DEV)
+        db = torch.zeros(out, device=DEV)
+        ops.weight_grad(g, ldg, out, a, fin, n, dw, col0, db, "fp32")
+        runs.append((dw.clone(), db.clone()))
+        torch.randn(1 << 20, device=DEV).sum()
+    for dw, db in runs[1:]:
+        assert torch.equal(dw, runs[0][0]) and torch.equal(db, runs[0][1])
+    want = g[:, :out].double().t() @ a.double()
+    assert _close(runs[0][0][:, col0:], want.float(), 1e-5)
+    assert float(runs[0][0][:, :col0].abs().sum()) == 0.0
+    assert _close(runs[0][1], g[:, :out].double().sum(0).float(), 1e-5)
+
+
+def test_a_training_step_is_reproducible_bit_for_bit():
+    g, sd, dt = _problem(3000, 16, 128, 2, 3, seed=77)
+    grads = []
+    for _ in range(2):
+        model = graph_network.EncodeProcessDecode(128, 128, 2, 3, 3)
+        model.load_state_dict(sd)
+        model = model.to(DEV).train()
+        model.train_precision = "fp32x3"
+        pred = model(g)
+        mse = torch.nn.functional.mse_loss
+        (mse(pred["acceleration"], g.y_acc) + 0.5 * mse(pred["temp_rate"], g.y_temp_rate)).backward()
+        grads.append({k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None})
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 10
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
