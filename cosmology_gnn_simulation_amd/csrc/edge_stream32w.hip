@@ -663,7 +663,18 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
         step_last(std::false_type{}, std::true_type{}, ps_all, pd_all);
         ln_affine_w<true, DT, KA, 2 * DT>(acc, ev, inb[0], ring.lnbuf(lnpar ^ 1), h, lnst);
 
-        if (valid) store_tile<DT>(ev, e_out + tile * (32 * D), lane);
+        if (valid) {
+            // the final latents go past the caches (written once, not read again in this launch: as plain stores they
+            // push the P rows out of L2; -0.6 % in a same-box A/B)
+            float* const tb = e_out + tile * (32 * D);
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {ev[t][4 * g], ev[t][4 * g + 1], ev[t][4 * g + 2], ev[t][4 * g + 3]};
+                    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(tb + ((4 * t + g) * 64 + lane) * 4));
+                }
+        }
         if (tn < tr.end) {
             tile = tn;
         } else {
