@@ -439,10 +439,16 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
             ps[4 * SUB + c] = __builtin_bit_cast(
                 bf16x8, *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)(ps_read ^ ((unsigned)c << 4)));
     };
-    // ring pieces of this interval: the first NP slots of a block
-    auto pieces_first = [&](auto qc) __attribute__((always_inline)) {
-        constexpr int q = decltype(qc)::value;
-        if constexpr (q < NP) ring.piece(q);
+    // ring pieces of this interval: NP consecutive MFMA slots of the block
+#ifndef CGNN_W8_PIECE_SLOT
+#define CGNN_W8_PIECE_SLOT 16     // first MFMA slot of a 32-MFMA block that issues a ring piece (a piece has the rest of this
+                                  // interval and the whole next one to land; from slot 0: +0.7 % in a same-box A/B, 8: the
+                                  // same as 0, 24: the same as 16 -- the head of a block carries the fragment pipeline's start)
+#endif
+    auto pieces_at = [&](auto qc, auto mc) __attribute__((always_inline)) {      // blocks of M MFMAs: slots P0 .. P0 + NP - 1
+        constexpr int q = decltype(qc)::value, M = decltype(mc)::value;
+        constexpr int P0 = CGNN_W8_PIECE_SLOT + NP <= M ? CGNN_W8_PIECE_SLOT : M - NP;
+        if constexpr (q >= P0 && q < P0 + NP) ring.piece(q - P0);
     };
 
     // A tile's per-lane inputs: the sender rows' byte offsets for the staging gathers, the receiver chunk's offset and (ENC)
@@ -567,7 +573,7 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
             // barrier instead of opening the next step with an LDS round trip)
             wblockw<DT, KS0>(acc, in0, base, make_fill([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value, t = q / KS0 - 1, w = q % KS0;
-                pieces_first(qc);
+                pieces_at(qc, CGNN_IC(DT * KS0));
                 if constexpr (t >= 0 && w == (KS0 > 2 ? 1 : KS0 - 1)) packw_slice<true, DT, (t < 0 ? 0 : t), 0>(inb[1], acc);
                 if constexpr (t >= 0 && w == (KS0 > 4 ? 3 : KS0 - 1)) {
                     packw_slice<true, DT, (t < 0 ? 0 : t), 1>(inb[1], acc);
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
             CGNN_W8_STAMP(14);
             wblockw<DT, KS>(acc, inb[l & 1], ring.base(), make_fill([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value, t = q / KS - 1, w = q % KS;
-                pieces_first(qc);
+                pieces_at(qc, CGNN_IC(DT * KS));
                 if constexpr (t >= 0 && w == (KS > 2 ? 1 : KS - 1)) packw_slice<true, DT, (t < 0 ? 0 : t), 0>(inb[(l + 1) & 1], acc);
                 if constexpr (t >= 0 && w == (KS > 4 ? 3 : KS - 1)) {
                     packw_slice<true, DT, (t < 0 ? 0 : t), 1>(inb[(l + 1) & 1], acc);
@@ -610,9 +616,10 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
             ln_sums_clear(sums);
             wblockw<DT, KS>(acc, inb[NH & 1], ring.base(), make_fill([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value, t = q / KS - 1, w = q % KS;
-                pieces_first(qc);
-                if constexpr (WITH_P && q >= NP && q < NP + 4) stage_ps(CGNN_IC(0), CGNN_IC(q - NP), nps);
-                if constexpr (WITH_P && q == NP + 4) pdchunk = load_pd_chunk(npd, dchunk);
+                pieces_at(qc, CGNN_IC(DT * KS));
+                constexpr int PQ = CGNN_W8_PIECE_SLOT == 0 ? NP : 0;      // the P requests: behind the pieces, or in the first slots
+                if constexpr (WITH_P && q >= PQ && q < PQ + 4) stage_ps(CGNN_IC(0), CGNN_IC(q - PQ), nps);
+                if constexpr (WITH_P && q == PQ + 4) pdchunk = load_pd_chunk(npd, dchunk);
                 // LayerNorm's sums of a finished row tile, under the next row tile's MFMAs
                 if constexpr (t >= 0 && w == (KS > 2 ? 2 : KS - 1)) ln_sums_add<DT, (t < 0 ? 0 : t), 0>(sums, acc);
                 if constexpr (t >= 0 && w == (KS > 4 ? 4 : KS - 1)) ln_sums_add<DT, (t < 0 ? 0 : t), 1>(sums, acc);
