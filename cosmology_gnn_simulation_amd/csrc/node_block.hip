@@ -25,6 +25,9 @@ __global__ __launch_bounds__(CGNN_BLOCK) void node_block_kernel(MlpDev m, const 
     for (int64_t tile = tr.first; tile < tr.end; tile += tr.stride) {
         const int64_t row = tile * 32 + r;
         const int64_t rowc = row < n ? row : n - 1;
+        // At latent 256 the f32 tile of x (128 registers) is NOT kept for the residual: it is read again at the end (from L2,
+        // 32 KiB per tile) -- kept, the two-fp16-term kernel spilled 192 registers (772 bytes of scratch per lane and tile)
+        constexpr bool RELOAD_X = DT >= 8;
         f32x16 xv[DT];
         load_rows_full<DT>(xv, x + rowc * D, h);
         Operand<PREC, HT> oph;
@@ -50,6 +53,7 @@ __global__ __launch_bounds__(CGNN_BLOCK) void node_block_kernel(MlpDev m, const 
         layer_norm_rows<DT>(out, m.gamma, m.beta, h);
         if (row < n) {
             if (residual) {
+                if constexpr (RELOAD_X) load_rows_full<DT>(xv, x + rowc * D, h);
 #pragma unroll
                 for (int t = 0; t < DT; ++t) out[t] += xv[t];
             }
