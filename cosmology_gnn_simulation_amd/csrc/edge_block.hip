@@ -52,6 +52,9 @@ __global__ __launch_bounds__(CGNN_BLOCK) void edge_block_kernel(MlpDev m,
         // whole tiles are stored: rows past num_edges are padding of the TILED32 buffer
         if (e_upd != nullptr) store_tile<DT>(out, e_upd + tile * (32 * D), lane);
         if (residual) {
+            // latent 256: the tile is not held through the MLP (128 registers: the kernel spilled 143-206 of them) but read
+            // again here, from L2 (this wave is the only writer of the tile, and it writes below)
+            if constexpr (DT >= 8) load_tile<DT>(ev, e_in + tile * (32 * D), lane);
 #pragma unroll
             for (int t = 0; t < DT; ++t) out[t] += ev[t];
         }
