@@ -79,7 +79,9 @@ __device__ __forceinline__ u32x4 load16_s(const void* base, unsigned voff) {
                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
     u32x4 r;
     // s_nop 4: the v_readfirstlane above is a VALU write of the SGPR pair this load reads (five wait states)
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sb) : "memory");
+    // nt: the edge latents stream through once per round (32.8 GB at cfg5's shape); kept out of the caches they leave L2 to
+    // the gathered P rows (loads and stores nt: 19.09 -> 18.52 ms per round)
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 nt" : "=v"(r) : "v"(voff), "s"(sb) : "memory");
     return r;
 }
 __device__ __forceinline__ int idx_load(const int32_t* p) {
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(CGNN_R256_BLOCK) void edge_block_ring256_kernel(Rin
             constexpr int o = decltype(oc)::value;
             if constexpr (o == OT - 1) pdn[KS - 1] = load16<(KS - 1) * 64>(dp);
             if (a.residual) acc[o] += ev[o];
-            if (valid) *reinterpret_cast<f32x4*>(a.e_out + tb + n16_tile_offset(o)) = acc[o];
+            if (valid) __builtin_nontemporal_store(acc[o], reinterpret_cast<f32x4*>(a.e_out + tb + n16_tile_offset(o)));
             if constexpr (o < KS) psn[o] = load16<o * 64>(pp);
             else if constexpr (o < OT - 1) pdn[o - KS] = load16<(o - KS) * 64>(dp);
         }, std::make_integer_sequence<int, OT>{});
