@@ -43,6 +43,18 @@ namespace cgnn {
 #ifndef CGNN_W8_LN_EARLY
 #define CGNN_W8_LN_EARLY 0    // LayerNorm affine slices (of 2 * latent / 32) done in the output layer's own step, before the barrier
 #endif
+// MFMA slots (within the next row tile's eight) that carry a finished row tile's pack halves / LayerNorm sums.  One slot
+// later than "as early as possible" (1, 3 / 2, 4): the vector instructions then read accumulators whose last MFMA is one
+// more MFMA old and issue without the wait (hipcc had padded them with s_nop 8 / 11): -1.5 % in same-box A/Bs.  (Holding the
+// second-to-last row tile's share back for the end of the block, to have work under the last MFMA's latency: +0.3 .. 1.2 %.)
+#ifndef CGNN_W8_PK0
+#define CGNN_W8_PK0 2
+#define CGNN_W8_PK1 4
+#endif
+#ifndef CGNN_W8_SM0
+#define CGNN_W8_SM0 4
+#define CGNN_W8_SM1 6
+#endif
 #ifndef CGNN_W8_PD
 #define CGNN_W8_PD 2       // groups in flight ahead of the MFMAs
 #endif
@@ -574,8 +586,8 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
             wblockw<DT, KS0>(acc, in0, base, make_fill([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value, t = q / KS0 - 1, w = q % KS0;
                 pieces_at(qc, CGNN_IC(DT * KS0));
-                if constexpr (t >= 0 && w == (KS0 > 2 ? 1 : KS0 - 1)) packw_slice<true, DT, (t < 0 ? 0 : t), 0>(inb[1], acc);
-                if constexpr (t >= 0 && w == (KS0 > 4 ? 3 : KS0 - 1)) {
+                if constexpr (t >= 0 && w == (KS0 > 4 ? CGNN_W8_PK0 : (KS0 > 2 ? 1 : KS0 - 1))) packw_slice<true, DT, (t < 0 ? 0 : t), 0>(inb[1], acc);
+                if constexpr (t >= 0 && w == (KS0 > 4 ? CGNN_W8_PK1 : KS0 - 1)) {
                     packw_slice<true, DT, (t < 0 ? 0 : t), 1>(inb[1], acc);
                     bias_rowsw<DT, (t < 0 ? 0 : t), (t < 0 ? 0 : t) + 1>(acc, ring.vec_addr(), h);
                 }
@@ -594,8 +606,8 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
             wblockw<DT, KS>(acc, inb[l & 1], ring.base(), make_fill([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value, t = q / KS - 1, w = q % KS;
                 pieces_at(qc, CGNN_IC(DT * KS));
-                if constexpr (t >= 0 && w == (KS > 2 ? 1 : KS - 1)) packw_slice<true, DT, (t < 0 ? 0 : t), 0>(inb[(l + 1) & 1], acc);
-                if constexpr (t >= 0 && w == (KS > 4 ? 3 : KS - 1)) {
+                if constexpr (t >= 0 && w == (KS > 4 ? CGNN_W8_PK0 : (KS > 2 ? 1 : KS - 1))) packw_slice<true, DT, (t < 0 ? 0 : t), 0>(inb[(l + 1) & 1], acc);
+                if constexpr (t >= 0 && w == (KS > 4 ? CGNN_W8_PK1 : KS - 1)) {
                     packw_slice<true, DT, (t < 0 ? 0 : t), 1>(inb[(l + 1) & 1], acc);
                     bias_rowsw<DT, (t < 0 ? 0 : t), (t < 0 ? 0 : t) + 1>(acc, ring.vec_addr(), h);
                 }
@@ -621,8 +633,8 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
                 if constexpr (WITH_P && q >= PQ && q < PQ + 4) stage_ps(CGNN_IC(0), CGNN_IC(q - PQ), nps);
                 if constexpr (WITH_P && q == PQ + 4) pdchunk = load_pd_chunk(npd, dchunk);
                 // LayerNorm's sums of a finished row tile, under the next row tile's MFMAs
-                if constexpr (t >= 0 && w == (KS > 2 ? 2 : KS - 1)) ln_sums_add<DT, (t < 0 ? 0 : t), 0>(sums, acc);
-                if constexpr (t >= 0 && w == (KS > 4 ? 4 : KS - 1)) ln_sums_add<DT, (t < 0 ? 0 : t), 1>(sums, acc);
+                if constexpr (t >= 0 && w == (KS > 4 ? CGNN_W8_SM0 : (KS > 2 ? 2 : KS - 1))) ln_sums_add<DT, (t < 0 ? 0 : t), 0>(sums, acc);
+                if constexpr (t >= 0 && w == (KS > 4 ? CGNN_W8_SM1 : KS - 1)) ln_sums_add<DT, (t < 0 ? 0 : t), 1>(sums, acc);
             }));
             CGNN_W8_STAMP(2);
             // LayerNorm: the statistics and the first KA affine slices here (vectors straight from this chunk), the rest behind
