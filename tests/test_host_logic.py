@@ -260,3 +260,13 @@ def test_committed_pmc_traffic_belongs_to_the_committed_kernels():
     assert not stale, f"re-run scripts/profile_round.sh: PMC traffic entries measured on older kernel sources: {stale}"
     for key in ("edge_stream+enc:1000000:16:128:10", "node_block:1000000:128", "aggregate:1000000:16:128"):
         assert bench._traffic(key, "") and bench._traffic(key, "") > 0, key
+
+
+def test_integration_notes_name_every_abi_entry():
+    """INTEGRATION.md's table is where a maintainer of the reference looks up what each C entry replaces: every function
+    include/cgnn.h declares must appear there."""
+    header = open(os.path.join(ROOT, "include", "cgnn.h")).read()
+    declared = set(re.findall(r"\b(cgnn_[a-z0-9_]+)\s*\(", header))
+    notes = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert len(declared) > 30
+    assert [d for d in sorted(declared) if d not in notes] == []
