@@ -58,6 +58,22 @@ namespace cgnn {
 #ifndef CGNN_W8_PD
 #define CGNN_W8_PD 2       // groups in flight ahead of the MFMAs
 #endif
+#ifndef CGNN_W8_PF16_INBLK
+#define CGNN_W8_PF16_INBLK 1
+#endif
+#ifndef CGNN_W8_ADDP0     // slots (within a row tile's eight) that carry the next row tile's P sums, eight values each
+#define CGNN_W8_ADDP0 5
+#define CGNN_W8_ADDP1 6
+#endif
+#ifndef CGNN_W8_LN_PHASED
+#define CGNN_W8_LN_PHASED 1
+#endif
+#ifndef CGNN_W8_REQ_EARLY
+#define CGNN_W8_REQ_EARLY 1   // a round's layer-0 fragments requested before its selector MFMAs
+#endif
+#ifndef CGNN_W8_CARRY
+#define CGNN_W8_CARRY 1    // LAG 0: the ring's barrier vouches for chunk g + 2 (not g + 1), the LDS fragment pipeline runs across steps
+#endif
 
 #ifdef CGNN_W8_STAMPS   // developer build: per-phase cycle sums (s_memtime into scalar registers, no memory traffic inside the
                         // loop) of one workgroup's waves, printed by the launcher
@@ -121,6 +137,9 @@ struct RingW {
         : image(img), count(cnt), wave(w), lane(l), slot(0), dma_chunk(0), dma_slot(0) {}
     __device__ __forceinline__ unsigned lds0() const { return (unsigned)(uintptr_t)(LdsWeightPtr)(cgnn_smem); }
     __device__ __forceinline__ unsigned base() const { return lds0() + (unsigned)slot * W::STRIDE; }
+    __device__ __forceinline__ unsigned base_next() const {
+        return lds0() + (unsigned)(slot + 1 == CGNN_W8_SLOTS ? 0 : slot + 1) * W::STRIDE;
+    }
     __device__ __forceinline__ unsigned vec_addr() const { return base() + W::VEC_OFF; }
     __device__ __forceinline__ unsigned lnbuf(int which) const { return lds0() + W::LNBUF_OFF + (unsigned)which * W::LNBUF_BYTES; }
     __device__ __forceinline__ void piece(int i) {
@@ -150,13 +169,16 @@ struct RingW {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
-    // End of an interval.  EXTRA (LAG 0) = vector-memory operations other than ring pieces this wave has issued in this
-    // interval (they are newer than the pieces waited for; a smaller count than the true one only waits longer).
+    // End of an interval.  EXTRA (LAG 0) = vector-memory operations this wave has issued in this interval BEHIND its ring
+    // pieces (they are newer than the pieces waited for; a smaller count than the true one only waits longer).
     // K0: first of this call's three timer slots (developer builds).
     template <int EXTRA, int K0 = 17>
     __device__ __forceinline__ void interval_end() {
         CGNN_W8_STAMP(K0);
-        vm_wait_const<(LAG ? 0 : W::NP + EXTRA)>();
+#ifdef CGNN_W8_SLEEP      // developer probe: idle cycles per interval (is the kernel bound by cycles or by the clock it is given?)
+        __builtin_amdgcn_s_sleep(CGNN_W8_SLEEP);
+#endif
+        vm_wait_const<(LAG ? 0 : (CGNN_W8_CARRY ? EXTRA : W::NP + EXTRA))>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         CGNN_W8_STAMP(K0 + 1);
         __builtin_amdgcn_s_barrier();
@@ -180,33 +202,61 @@ __device__ __forceinline__ void lds_wait2(u32x4& a, u32x4& b) {
 // acc[o] += W[32 o .. 32 o + 31, :] . in ; fragment m = o * KS + ks (1 KiB, lane-linear) at addr + m * 1024, rows one
 // after the other.  Fragment reads and their counted waits by hand (hipcc waits lgkmcnt(0) before every group
 // otherwise); PD groups of GS fragments in flight ahead of the MFMAs.  `fill.run<m>()` runs right behind MFMA m.
-template <int NROW, int KS, class Fill>
-__device__ __forceinline__ void wblockw(f32x16 (&acc)[NROW], const bf16x8 (&in)[KS], unsigned addr, const Fill& fill) {
-    constexpr int M = NROW * KS, GS = (M % CGNN_W8_GS == 0) ? CGNN_W8_GS : 2, NG = M / GS, PD = CGNN_W8_PD, NBUF = PD + 1;
+// The fragment pipeline runs ACROSS blocks (round 4): the buffers live at kernel scope (FragBuf), group g of a block
+// sits in buffer (ROT + g) % NBUF, and a block with COUT requests the first PD groups of the NEXT chunk (addr_next)
+// behind its own last MFMAs -- the ring's barrier has vouched for that chunk one interval early (RingW, LAG 0) -- so that
+// the next block (CIN) starts on fragments that landed under this block's tail and the barrier instead of opening with
+// an exposed LDS round trip.
+struct FragBuf {
+    static constexpr int PD = CGNN_W8_PD, NBUF = PD + 1;
+    u32x4 b[NBUF][CGNN_W8_GS];
+};
+template <int M>
+struct WBlockGeom {
+    static constexpr int GS = CGNN_W8_GS, NG = M / GS;
     static_assert(M % GS == 0 && (GS == 4 || GS == 2), "groups of four or two fragments");
+    static constexpr int rot_after(int rot) { return (rot + NG) % FragBuf::NBUF; }
+};
+// the first PD groups of a block, requested ahead of it (before the selector MFMAs of a round's first step)
+template <int M, int ROT>
+__device__ __forceinline__ void wblock_request(FragBuf& fb, unsigned addr) {
+    constexpr int GS = WBlockGeom<M>::GS, NG = WBlockGeom<M>::NG, PD = FragBuf::PD, NBUF = FragBuf::NBUF;
     const unsigned a = addr + (unsigned)(threadIdx.x & 63) * 16u;
-    u32x4 buf[NBUF][GS];
     static_for_each([&](auto pc) __attribute__((always_inline)) {
         constexpr int p = decltype(pc)::value;
         if constexpr (p < NG) {
             static_for_each([&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
-                buf[p][j] = lds_read_b128<(p * GS + j) * 1024>(a);
+                fb.b[(ROT + p) % NBUF][j] = lds_read_b128<(p * GS + j) * 1024>(a);
             }, std::make_integer_sequence<int, GS>{});
         }
     }, std::make_integer_sequence<int, PD>{});
+}
+template <int NROW, int KS, int ROT, bool CIN, bool COUT, class Fill>
+__device__ __forceinline__ void wblockw(f32x16 (&acc)[NROW], const bf16x8 (&in)[KS], FragBuf& fb, unsigned addr, unsigned addr_next,
+                                        const Fill& fill) {
+    constexpr int M = NROW * KS, GS = WBlockGeom<M>::GS, NG = WBlockGeom<M>::NG, PD = FragBuf::PD, NBUF = FragBuf::NBUF;
+    static_assert(!COUT || NG >= PD, "a block that requests the next one's fragments is at least PD groups long");
+    const unsigned a = addr + (unsigned)(threadIdx.x & 63) * 16u;
+    const unsigned an = addr_next + (unsigned)(threadIdx.x & 63) * 16u;
+    (void)an;
+    if constexpr (!CIN) wblock_request<M, ROT>(fb, addr);
     static_for_each([&](auto gc) __attribute__((always_inline)) {
         constexpr int g = decltype(gc)::value;
-        constexpr int newer = ((g + PD - 1 < NG ? g + PD - 1 : NG - 1) - g) * GS;     // fragment reads issued after group g's
+        // fragment reads issued after group g's (and before this wait)
+        constexpr int newer = COUT ? (PD - 1) * GS : ((g + PD - 1 < NG ? g + PD - 1 : NG - 1) - g) * GS;
+        constexpr int bi = (ROT + g) % NBUF;
         if constexpr (GS == 4)
-            lds_wait4<newer>(buf[g % NBUF][0], buf[g % NBUF][1], buf[g % NBUF][2], buf[g % NBUF][3]);
+            lds_wait4<newer>(fb.b[bi][0], fb.b[bi][1], fb.b[bi][2], fb.b[bi][3]);
         else
-            lds_wait2<newer>(buf[g % NBUF][0], buf[g % NBUF][1]);
+            lds_wait2<newer>(fb.b[bi][0], fb.b[bi][1]);
         static_for_each([&](auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value, m = g * GS + j, o = m / KS, ks = m % KS;
-            acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, buf[g % NBUF][j]), in[ks], acc[o], 0, 0,
-                                                             0);
-            if constexpr (g + PD < NG) buf[(g + PD) % NBUF][j] = lds_read_b128<((g + PD) * GS + j) * 1024>(a);
+            acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb.b[bi][j]), in[ks], acc[o], 0, 0, 0);
+            if constexpr (g + PD < NG)
+                fb.b[(ROT + g + PD) % NBUF][j] = lds_read_b128<((g + PD) * GS + j) * 1024>(a);
+            else if constexpr (COUT)
+                fb.b[(ROT + g + PD) % NBUF][j] = lds_read_b128<((g + PD - NG) * GS + j) * 1024>(an);
             fill.template run<m>();
             __builtin_amdgcn_sched_barrier(0);
         }, std::make_integer_sequence<int, GS>{});
@@ -228,6 +278,9 @@ __device__ __forceinline__ void packw_slice(bf16x8 (&out)[2 * DT], const f32x16 
 // acc[t] = bias rows, t in [T0, T1) (plain LDS loads from a chunk's vector block)
 template <int DT, int T0, int T1>
 __device__ __forceinline__ void bias_rowsw(f32x16 (&acc)[DT], unsigned vec_addr, int h) {
+#ifdef CGNN_W8_ABL_BIAS    // developer timing build (wrong results): no bias reads
+    return;
+#endif
     const LdsVecPtr b = (LdsVecPtr)(uintptr_t)vec_addr;
 #pragma unroll
     for (int t = T0; t < T1; ++t)
@@ -311,6 +364,25 @@ __device__ __forceinline__ void ln_affine_w(const f32x16 (&acc)[DT], f32x16 (&ev
 #pragma unroll
             for (int i = 0; i < 8; ++i) ev[t][8 * s + i] += acc[t][8 * s + i];
 #else
+#if CGNN_W8_LN_PHASED
+            // the slice's eight values phase by phase (normalise | add beta and the residual | scale by gamma | pack), a
+            // scheduling barrier between the phases: every instruction's inputs are eight instructions old (as one chain
+            // per value hipcc reuses ONE temporary and each fmac waits for the add right in front of it)
+            float nrm[8], bs[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) nrm[i] = __builtin_fmaf(acc[t][8 * s + i], st.rstd, st.nmr);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bs[i] = RES ? bt[cur][i >> 2][i & 3] + ev[t][8 * s + i] : bt[cur][i >> 2][i & 3];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ev[t][8 * s + i] = __builtin_fmaf(nrm[i], gm[cur][i >> 2][i & 3], bs[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4 v;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) v[x] = pack_bf16(ev[t][8 * s + 2 * x], ev[t][8 * s + 2 * x + 1]);
+            in[2 * t + s] = __builtin_bit_cast(bf16x8, v);
+#else
             u32x4 v;
 #pragma unroll
             for (int gg = 0; gg < 2; ++gg) {
@@ -328,6 +400,7 @@ __device__ __forceinline__ void ln_affine_w(const f32x16 (&acc)[DT], f32x16 (&ev
             }
             in[2 * t + s] = __builtin_bit_cast(bf16x8, v);
 #endif
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }, std::make_integer_sequence<int, K1 - K0>{});
     }
@@ -337,6 +410,9 @@ __device__ __forceinline__ void ln_affine_w(const f32x16 (&acc)[DT], f32x16 (&ev
 template <int DT, int T0, int T1>
 __device__ __forceinline__ void selp_rows(f32x16 (&acc)[DT], const bf16x8 (&ps)[2 * DT], const bf16x8 (&pd)[2 * DT], bf16x8 sel0,
                                           bf16x8 sel1) {
+#ifdef CGNN_W8_ABL_SEL     // developer timing build (wrong results): no selector MFMAs
+    return;
+#endif
     static_for_each([&](auto tc) __attribute__((always_inline)) {
         constexpr int t = decltype(tc)::value + T0;
         f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -345,6 +421,45 @@ __device__ __forceinline__ void selp_rows(f32x16 (&acc)[DT], const bf16x8 (&ps)[
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel0, pd[2 * t], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sel1, pd[2 * t + 1], c, 0, 0, 0);
         acc[t] = c;
+    }, std::make_integer_sequence<int, T1 - T0>{});
+}
+
+// fp16 P tables (CGNN_P_F16_S32): acc[t][8 s + j] = Ps[src] + Pd[dst] on the vector pipe, ONE instruction per value --
+// v_fma_mix_f32 widens both fp16 halves on the way in (f32 sum of two fp16 numbers: exact up to the final f32 rounding) --
+// instead of four selector MFMAs per row tile (16 of the 112 MFMAs of a pass: with them ablated the kernel took 9.3 %
+// less time, with these 64 vector instructions in their place ... see DESIGN section 6).
+__device__ __forceinline__ float mix_add_lo(unsigned a, unsigned b) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float mix_add_hi(unsigned a, unsigned b) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int DT, int T, int S>
+__device__ __forceinline__ void addp_half(f32x16 (&acc)[DT], const bf16x8 (&ps)[2 * DT], const bf16x8 (&pd)[2 * DT]) {
+    const u32x4 a = __builtin_bit_cast(u32x4, ps[2 * T + S]), b = __builtin_bit_cast(u32x4, pd[2 * T + S]);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        acc[T][8 * S + 2 * x] = mix_add_lo(a[x], b[x]);
+        acc[T][8 * S + 2 * x + 1] = mix_add_hi(a[x], b[x]);
+    }
+}
+template <int DT, int T0, int T1>
+__device__ __forceinline__ void addp_rows(f32x16 (&acc)[DT], const bf16x8 (&ps)[2 * DT], const bf16x8 (&pd)[2 * DT]) {
+    static_for_each([&](auto tc) __attribute__((always_inline)) {
+        constexpr int t = decltype(tc)::value + T0;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const u32x4 a = __builtin_bit_cast(u32x4, ps[2 * t + s]), b = __builtin_bit_cast(u32x4, pd[2 * t + s]);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                acc[t][8 * s + 2 * x] = mix_add_lo(a[x], b[x]);
+                acc[t][8 * s + 2 * x + 1] = mix_add_hi(a[x], b[x]);
+            }
+        }
     }, std::make_integer_sequence<int, T1 - T0>{});
 }
 
@@ -358,7 +473,7 @@ __device__ __forceinline__ void selp_rows(f32x16 (&acc)[DT], const bf16x8 (&ps)[
 //   last step    bias, MFMAs (first half of the next pass's sender rows and the receiver rows requested from their first
 //                slots), LayerNorm statistics, (waves 0-3: LayerNorm vectors -> side buffer)
 // Ring pieces go out in the first MFMA slots of every step; every step ends with RingW::interval_end.
-template <int DT, int NH, bool ENC, int LAG>
+template <int DT, int NH, bool ENC, int LAG, bool PF16>
 __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
     S32Args a, const __bf16* __restrict__ ps_all, const __bf16* __restrict__ pd_all, int64_t round_stride,
     const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t num_edges, const float* e_in, float* e_out,
@@ -390,6 +505,16 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
     const bf16x8 sel0 = p32_selector(lane, 0), sel1 = p32_selector(lane, 1);
 
     f32x16 ev[DT], acc[DT];
+    FragBuf fb;
+    constexpr bool CARRY = CGNN_W8_CARRY && LAG == 0;
+    // buffer rotation of the fragment pipeline at layer l of a pass (ENC pass: the first Linear has two k-steps)
+    auto rot_at = [](bool enc_first, int l) constexpr -> int {
+        int r = 0;
+        if (l >= 1) r = enc_first ? WBlockGeom<DT * 2>::rot_after(0) : WBlockGeom<DT * KS>::rot_after(0);
+        for (int i = 1; i < l; ++i) r = WBlockGeom<DT * KS>::rot_after(r);
+        return r;
+    };
+    (void)rot_at;
     bf16x8 inb[2][2 * DT];      // layer l reads inb[l & 1] and packs into inb[(l + 1) & 1]; LayerNorm writes inb[0]
     bf16x8 ps[2 * DT], pd[2 * DT];
     int lnpar = 0;              // which side buffer holds the pending LayerNorm's vectors
@@ -417,6 +542,12 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
     auto read_pd = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2 * DT; ++i)
+            pd[i] = __builtin_bit_cast(bf16x8, *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)(pd_read + 16u * (unsigned)i));
+    };
+    auto read_pd_row = [&](auto tc) __attribute__((always_inline)) {      // the two pieces of row tile t
+        constexpr int t = decltype(tc)::value;
+#pragma unroll
+        for (int i = 2 * t; i < 2 * t + 2; ++i)
             pd[i] = __builtin_bit_cast(bf16x8, *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)(pd_read + 16u * (unsigned)i));
     };
     u32x4 pdchunk = {0u, 0u, 0u, 0u};
@@ -548,6 +679,10 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
             constexpr bool IS_ENC = decltype(enc_tag)::value;
             constexpr int PEND = decltype(pend_tag)::value;
             constexpr int KS0 = IS_ENC ? 2 : KS;     // the encoder's first Linear: K padded to one 32-wide k tile
+            // fp16 P tables: the sums Ps[src] + Pd[dst] of row tiles 1 .. DT - 1 ride in the MFMA slots of the row tile before
+            // (three hidden layers: the pieces read just in time inside the block cost four spilled registers; there the sums
+            // stay in front of the block)
+            constexpr bool INBLK = PF16 && CGNN_W8_PF16_INBLK && NH <= 2 && !IS_ENC && PEND != 0;
             CGNN_W8_STAMP(8);
             if constexpr (PEND != 0) {
                 if constexpr (!IS_ENC) {
@@ -564,28 +699,55 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
                 // (measured and dropped: the selector MFMAs of a row tile right behind its two LayerNorm slices, so that they
                 // run under the next slices' vector work: no gain, four spilled registers)
                 ln_affine_w<PEND == 2, DT, KA, 2 * DT>(acc, ev, inb[0], ring.lnbuf(lnpar ^ 1), h, lnst);
-                if constexpr (!IS_ENC) read_pd();
+                if constexpr (!IS_ENC) {
+                    if constexpr (INBLK) read_pd_row(CGNN_IC(0)); else read_pd();
+                }
             }
             const unsigned base = ring.base();
             CGNN_W8_STAMP(9);
+            // layer 0's first fragment groups land under the selector MFMAs
+            constexpr bool REQ = CARRY && !IS_ENC && CGNN_W8_REQ_EARLY;
+            if constexpr (REQ) wblock_request<DT * KS0, 0>(fb, base);
             if constexpr (IS_ENC) {
                 bias_rowsw<DT, 0, DT>(acc, ring.vec_addr() + (unsigned)D * 4u, h);      // the encoder's first bias: vector 1 of its own chunk
             } else if constexpr (PEND != 0) {
-                selp_rows<DT, 0, DT / 2>(acc, ps, pd, sel0, sel1);
-                CGNN_S32_VMCNT(0);      // the second half of the sender rows (requested a LayerNorm ago; nothing newer in flight)
-                read_ps(CGNN_IC(1));
-                selp_rows<DT, DT / 2, DT>(acc, ps, pd, sel0, sel1);
+                if constexpr (INBLK) {
+                    addp_rows<DT, 0, 1>(acc, ps, pd);      // row tile 0 here, the others from the MFMA slots of the block below
+                } else if constexpr (PF16) {
+                    addp_rows<DT, 0, DT / 2>(acc, ps, pd);
+                    CGNN_S32_VMCNT(0);      // the second half of the sender rows (requested a LayerNorm ago; nothing newer in flight)
+                    read_ps(CGNN_IC(1));
+                    addp_rows<DT, DT / 2, DT>(acc, ps, pd);
+                } else {
+                    selp_rows<DT, 0, DT / 2>(acc, ps, pd, sel0, sel1);
+                    CGNN_S32_VMCNT(0);      // the second half of the sender rows (requested a LayerNorm ago; nothing newer in flight)
+                    read_ps(CGNN_IC(1));
+                    selp_rows<DT, DT / 2, DT>(acc, ps, pd, sel0, sel1);
+                }
             } else {
-                selp_rows<DT, 0, DT>(acc, ps, pd, sel0, sel1);
+                if constexpr (PF16) addp_rows<DT, 0, DT>(acc, ps, pd);
+                else selp_rows<DT, 0, DT>(acc, ps, pd, sel0, sel1);
             }
             CGNN_W8_STAMP(10);
             const bf16x8 (&in0)[KS0] = reinterpret_cast<const bf16x8(&)[KS0]>(inb[0][0]);
             // each finished row tile is packed under the next one's MFMAs, and its accumulators take the NEXT layer's bias
             // (vector 0 of this chunk: the image stores every bias one chunk early, so that these reads are over before the
             // barrier instead of opening the next step with an LDS round trip)
-            wblockw<DT, KS0>(acc, in0, base, make_fill([&](auto qc) __attribute__((always_inline)) {
+            wblockw<DT, KS0, 0, REQ, CARRY>(acc, in0, fb, base, ring.base_next(), make_fill([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value, t = q / KS0 - 1, w = q % KS0;
                 pieces_at(qc, CGNN_IC(DT * KS0));
+                if constexpr (INBLK && t + 2 < DT) {      // row tile tn = t + 2 while row tile t + 1 runs its MFMAs
+                    constexpr int tn = t + 2 < DT ? t + 2 : 0;
+                    if constexpr (w == 0) {
+                        if constexpr (tn == DT / 2) {
+                            CGNN_S32_VMCNT(0);      // the second half of the sender rows (requested a LayerNorm ago)
+                            read_ps(CGNN_IC(1));
+                        }
+                        read_pd_row(CGNN_IC(tn));
+                    }
+                    if constexpr (w == CGNN_W8_ADDP0) addp_half<DT, tn, 0>(acc, ps, pd);
+                    if constexpr (w == CGNN_W8_ADDP1) addp_half<DT, tn, 1>(acc, ps, pd);
+                }
                 if constexpr (t >= 0 && w == (KS0 > 4 ? CGNN_W8_PK0 : (KS0 > 2 ? 1 : KS0 - 1))) packw_slice<true, DT, (t < 0 ? 0 : t), 0>(inb[1], acc);
                 if constexpr (t >= 0 && w == (KS0 > 4 ? CGNN_W8_PK1 : KS0 - 1)) {
                     packw_slice<true, DT, (t < 0 ? 0 : t), 1>(inb[1], acc);
@@ -600,10 +762,11 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
             ring.advance();
         };
         // hidden layer l (1 .. NH - 1)
-        auto step_hidden = [&](auto lc) __attribute__((always_inline)) {
+        auto step_hidden = [&](auto enc_tag, auto lc) __attribute__((always_inline)) {
             constexpr int l = decltype(lc)::value;
+            constexpr bool IS_ENC = decltype(enc_tag)::value;
             CGNN_W8_STAMP(14);
-            wblockw<DT, KS>(acc, inb[l & 1], ring.base(), make_fill([&](auto qc) __attribute__((always_inline)) {
+            wblockw<DT, KS, rot_at(IS_ENC, l), CARRY, CARRY>(acc, inb[l & 1], fb, ring.base(), ring.base_next(), make_fill([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value, t = q / KS - 1, w = q % KS;
                 pieces_at(qc, CGNN_IC(DT * KS));
                 if constexpr (t >= 0 && w == (KS > 4 ? CGNN_W8_PK0 : (KS > 2 ? 1 : KS - 1))) packw_slice<true, DT, (t < 0 ? 0 : t), 0>(inb[(l + 1) & 1], acc);
@@ -620,13 +783,13 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
             ring.advance();
         };
         // output layer; WITH_P: request the next pass's P rows (tables nps / npd) from the slots behind the ring pieces
-        auto step_last = [&](auto p_tag, auto res_tag, const __bf16* nps, const __bf16* npd) __attribute__((always_inline)) {
-            constexpr bool WITH_P = decltype(p_tag)::value, RES = decltype(res_tag)::value;
+        auto step_last = [&](auto enc_tag, auto p_tag, auto res_tag, const __bf16* nps, const __bf16* npd) __attribute__((always_inline)) {
+            constexpr bool WITH_P = decltype(p_tag)::value, RES = decltype(res_tag)::value, IS_ENC = decltype(enc_tag)::value;
             CGNN_W8_STAMP(0);
             CGNN_W8_STAMP(1);
             LnSums sums;
             ln_sums_clear(sums);
-            wblockw<DT, KS>(acc, inb[NH & 1], ring.base(), make_fill([&](auto qc) __attribute__((always_inline)) {
+            wblockw<DT, KS, rot_at(IS_ENC, NH), CARRY, false>(acc, inb[NH & 1], fb, ring.base(), 0u, make_fill([&](auto qc) __attribute__((always_inline)) {
                 constexpr int q = decltype(qc)::value, t = q / KS - 1, w = q % KS;
                 pieces_at(qc, CGNN_IC(DT * KS));
                 constexpr int PQ = CGNN_W8_PIECE_SLOT == 0 ? NP : 0;      // the P requests: behind the pieces, or in the first slots
@@ -655,31 +818,33 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
             }
             lnpar ^= 1;
             ring.dma_done();
-            ring.template interval_end<(WITH_P ? 5 : 0), 3>();
+            ring.template interval_end<(WITH_P && (!CARRY || CGNN_W8_PIECE_SLOT == 0) ? 5 : 0), 3>();
             ring.advance();
         };
-        auto hidden_steps = [&]() __attribute__((always_inline)) {
+        auto hidden_steps = [&](auto enc_tag) __attribute__((always_inline)) {
             static_for_each([&](auto lc) __attribute__((always_inline)) {
-                step_hidden(std::integral_constant<int, decltype(lc)::value + 1>{});
+                step_hidden(enc_tag, std::integral_constant<int, decltype(lc)::value + 1>{});
             }, std::make_integer_sequence<int, NH - 1>{});
         };
+        constexpr std::true_type ENC_PASS{};
+        constexpr std::false_type ROUND_PASS{};
 
         if (ENC) {
-            step_first(std::true_type{}, CGNN_IC(0), 0);
-            hidden_steps();
-            step_last(std::true_type{}, std::false_type{}, ps_all, pd_all);
-            step_first(std::false_type{}, CGNN_IC(1), 0);
-            hidden_steps();
+            step_first(ENC_PASS, CGNN_IC(0), 0);
+            hidden_steps(ENC_PASS);
+            step_last(ENC_PASS, std::true_type{}, std::false_type{}, ps_all, pd_all);
+            step_first(ROUND_PASS, CGNN_IC(1), 0);
+            hidden_steps(ROUND_PASS);
         } else {
-            step_first(std::false_type{}, CGNN_IC(0), 0);
-            hidden_steps();
+            step_first(ROUND_PASS, CGNN_IC(0), 0);
+            hidden_steps(ROUND_PASS);
         }
         for (int rr = 1; rr < L; ++rr) {
-            step_last(std::true_type{}, std::true_type{}, ps_all + (int64_t)rr * round_stride, pd_all + (int64_t)rr * round_stride);
-            step_first(std::false_type{}, CGNN_IC(2), rr);
-            hidden_steps();
+            step_last(ROUND_PASS, std::true_type{}, std::true_type{}, ps_all + (int64_t)rr * round_stride, pd_all + (int64_t)rr * round_stride);
+            step_first(ROUND_PASS, CGNN_IC(2), rr);
+            hidden_steps(ROUND_PASS);
         }
-        step_last(std::false_type{}, std::true_type{}, ps_all, pd_all);
+        step_last(ROUND_PASS, std::false_type{}, std::true_type{}, ps_all, pd_all);
         ln_affine_w<true, DT, KA, 2 * DT>(acc, ev, inb[0], ring.lnbuf(lnpar ^ 1), h, lnst);
 
         if (valid) {
@@ -709,13 +874,13 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
     __builtin_amdgcn_s_barrier();
 }
 
-template <int DT, int NH, int LAG>
+template <int DT, int NH, int LAG, bool PF16>
 static int launch_w8(const S32Args& a, const __bf16* ps, const __bf16* pd, int64_t round_stride, const int32_t* src,
                      const int32_t* dst, int64_t num_edges, const float* e_in, float* e_out, const float* attr, int ld_attr,
                      int seg_k, hipStream_t st) {
     typedef W8Geom<DT> W;
     const bool enc = a.enc_in_dim > 0;
-    auto kern = enc ? edge_stream32w_kernel<DT, NH, true, LAG> : edge_stream32w_kernel<DT, NH, false, LAG>;
+    auto kern = enc ? edge_stream32w_kernel<DT, NH, true, LAG, PF16> : edge_stream32w_kernel<DT, NH, false, LAG, PF16>;
     if (W::LDS > 48 * 1024) {
         int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), W::LDS, "hipFuncSetAttribute(edge_stream32w)");
         if (rc != CGNN_OK) return rc;
@@ -792,11 +957,20 @@ extern "C" int cgnn_edge_stream_run_w8(const void* image, size_t image_bytes, in
                                        int32_t num_rounds, int32_t enc_in_dim, const void* ps_all, const void* pd_all,
                                        int64_t round_stride, const int32_t* src, const int32_t* dst, int64_t num_edges,
                                        const float* e_in, float* e_out, const float* edge_attr, int32_t ld_attr, int32_t lag,
-                                       int32_t fixed_k, void* stream) {
+                                       int32_t fixed_k, int32_t p_format, void* stream) {
     if (!image || !ps_all || !pd_all || !src || !dst || !e_out || num_edges < 0 || num_rounds < 1 || num_hidden_layers < 1 ||
         round_stride < 0 || (enc_in_dim > 0 ? (!edge_attr || ld_attr < enc_in_dim) : !e_in) || lag < 0 || lag > 1 || fixed_k < 0) {
         set_error("cgnn_edge_stream_run_w8: invalid argument");
         return CGNN_ERR_INVALID_ARG;
+    }
+    if (p_format != CGNN_P_BF16_S32 && p_format != CGNN_P_F16_S32) {
+        set_error("cgnn_edge_stream_run_w8: ps_all / pd_all must be CGNN_P_F16_S32 or CGNN_P_BF16_S32 tables (got p_format %d)",
+                  p_format);
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if (p_format == CGNN_P_F16_S32 && lag != 0) {
+        set_error("cgnn_edge_stream_run_w8: fp16 tables (CGNN_P_F16_S32) run with lag = 0 (lag = 1 is kept for bf16 tables)");
+        return CGNN_ERR_UNSUPPORTED;
     }
     if (enc_in_dim > 4 || (enc_in_dim > 0 && ((ld_attr & 3) != 0 || ((uintptr_t)edge_attr & 15) != 0))) {
         set_error("cgnn_edge_stream_run_w8: the in-launch encoder reads an edge's features with one aligned 16-byte load: at most "
@@ -822,20 +996,27 @@ extern "C" int cgnn_edge_stream_run_w8(const void* image, size_t image_bytes, in
     a.nh = num_hidden_layers;
     a.enc_in_dim = enc_in_dim > 0 ? enc_in_dim : 0;
     hipStream_t st = (hipStream_t)stream;
-#define CGNN_W8_GO(NHx, LAGx)                                                                                                \
-    return launch_w8<4, NHx, LAGx>(a, (const __bf16*)ps_all, (const __bf16*)pd_all, round_stride, src, dst, num_edges, e_in, \
-                                   e_out, edge_attr, ld_attr, fixed_k, st)
+#define CGNN_W8_GO(NHx, LAGx, PFx)                                                                                               \
+    return launch_w8<4, NHx, LAGx, PFx>(a, (const __bf16*)ps_all, (const __bf16*)pd_all, round_stride, src, dst, num_edges, e_in, \
+                                        e_out, edge_attr, ld_attr, fixed_k, st)
+    if (p_format == CGNN_P_F16_S32) {
+        switch (num_hidden_layers) {
+            case 1: CGNN_W8_GO(1, 0, true);
+            case 2: CGNN_W8_GO(2, 0, true);
+            default: CGNN_W8_GO(3, 0, true);
+        }
+    }
     if (lag) {
         switch (num_hidden_layers) {
-            case 1: CGNN_W8_GO(1, 1);
-            case 2: CGNN_W8_GO(2, 1);
-            default: CGNN_W8_GO(3, 1);
+            case 1: CGNN_W8_GO(1, 1, false);
+            case 2: CGNN_W8_GO(2, 1, false);
+            default: CGNN_W8_GO(3, 1, false);
         }
     }
     switch (num_hidden_layers) {
-        case 1: CGNN_W8_GO(1, 0);
-        case 2: CGNN_W8_GO(2, 0);
-        default: CGNN_W8_GO(3, 0);
+        case 1: CGNN_W8_GO(1, 0, false);
+        case 2: CGNN_W8_GO(2, 0, false);
+        default: CGNN_W8_GO(3, 0, false);
     }
 #undef CGNN_W8_GO
 }

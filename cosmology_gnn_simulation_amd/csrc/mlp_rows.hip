@@ -286,9 +286,16 @@ int cgnn_project_nodes(const cgnn_linear* ws, const cgnn_linear* wd, int32_t pre
     const float* bd = pd ? wd->b : nullptr;
     const bool f32_like = precision == CGNN_F32 || precision == CGNN_F16X2;     // both write CGNN_P_F32 tables
     if (f32_like != (p_format == CGNN_P_F32) || (!f32_like && precision != CGNN_BF16) ||
-        (p_format != CGNN_P_F32 && p_format != CGNN_P_BF16_S32 && p_format != CGNN_P_BF16_S16)) {
+        (p_format != CGNN_P_F32 && p_format != CGNN_P_BF16_S32 && p_format != CGNN_P_BF16_S16 && p_format != CGNN_P_F16_S32)) {
         set_error("cgnn_project_nodes: precision %d / p_format %d combination is not supported", precision, p_format);
         return CGNN_ERR_INVALID_ARG;
+    }
+    if (p_format == CGNN_P_F16_S32) {      // the table format of cgnn_edge_stream_run_w8: built where that kernel is
+        if (HT != 4 || DT != 4) {
+            set_error("cgnn_project_nodes: CGNN_P_F16_S32 tables are built for latent = hidden = 128 (got %d, %d)", D, H);
+            return CGNN_ERR_UNSUPPORTED;
+        }
+        return launch_project<CGNN_BF16, CGNN_P_F16_S32, 4, 4>(wsp, wdp, bd, H, x, n, ps, pd, st);
     }
 #define CGNN_PAIR(Hh, Dd)                                                                                          \
     if (HT == Hh && DT == Dd) {                                                                                     \

@@ -256,7 +256,7 @@ extern "C" int cgnn_node_block(const cgnn_mlp* mlp, const cgnn_linear* w_x, cons
             const bool shapes = ws_next->in_dim == latent && ws_next->out_dim == latent && wd_next->in_dim == latent &&
                                 wd_next->out_dim == latent;
             fuse = shapes && proj_precision == CGNN_BF16_N16 &&
-                   (p_format == CGNN_P_BF16_S32 || p_format == CGNN_P_BF16_S16);
+                   (p_format == CGNN_P_BF16_S32 || p_format == CGNN_P_BF16_S16 || (p_format == CGNN_P_F16_S32 && DT == 4));
             if (!fuse && proj_precision == CGNN_BF16_N16) {
                 set_error("cgnn_node_block: CGNN_BF16_N16 projection weights can only be used fused (square, bf16 table)");
                 return CGNN_ERR_UNSUPPORTED;

@@ -235,17 +235,26 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
         // CGNN_P_BF16_S32 rows (feature 32t + 8g + 4h + i at h * 64 + (4t + g) * 4 + i): tile O of lane (c, q) is 8 bytes at
         // h = q & 1, 4t + g = 4 (O >> 1) + 2 (O & 1) + (q >> 1); four tiles fill 64 bytes of each half of the row
         auto store_p = [&](const f32x4 (&acc)[OT], __bf16* base) {
-            if constexpr (PFMT == CGNN_P_BF16_S32) {
+            if constexpr (PFMT == CGNN_P_BF16_S32 || PFMT == CGNN_P_F16_S32) {
                 char* const pt = reinterpret_cast<char*>(base + (tile_row + (lane >> 3)) * D) + ((lane & 7) >> 2) * 128 +
                                  (lane & 3) * 16;
 #pragma unroll
                 for (int pp = 0; pp < OT / 4; ++pp) {
 #pragma unroll
                     for (int oo = 0; oo < 4; ++oo) {
-                        bf16x4 v;
+                        char* const sp = stage + c * 128 + (q & 1) * 64 + (4 * (oo >> 1) + 2 * (oo & 1) + (q >> 1)) * 8;
+                        if constexpr (PFMT == CGNN_P_F16_S32) {      // the same order, fp16 values
+                            typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+                            f16x4v v;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = (__bf16)acc[4 * pp + oo][i];
-                        *(LdsB4Ptr)(stage + c * 128 + (q & 1) * 64 + (4 * (oo >> 1) + 2 * (oo & 1) + (q >> 1)) * 8) = v;
+                            for (int i = 0; i < 4; ++i) v[i] = (_Float16)acc[4 * pp + oo][i];
+                            *(__attribute__((address_space(3))) f16x4v*)sp = v;
+                        } else {
+                            bf16x4 v;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = (__bf16)acc[4 * pp + oo][i];
+                            *(LdsB4Ptr)sp = v;
+                        }
                     }
                     const LdsU4Ptr r = (LdsU4Ptr)(stage + lane * 16);
                     const u32x4 v0 = r[0], v1 = r[64];
@@ -353,11 +362,12 @@ int node_block_f2ring(const MlpDev& m, const cgnn_linear* w_x, const cgnn_linear
     a.n = n;
     a.steps = steps;
     a.residual = residual;
-    const bool s16 = fuse && p_format == CGNN_P_BF16_S16;
+    const bool s16 = fuse && p_format == CGNN_P_BF16_S16, f16 = fuse && p_format == CGNN_P_F16_S32;
     int rc = CGNN_ERR_UNSUPPORTED;
 #define CGNN_GO(NHh)                                                                                       \
     if (m.nh == NHh)                                                                                        \
-        rc = s16 ? launch_f2ring<NHh, CGNN_P_BF16_S16>(a, st) : launch_f2ring<NHh, CGNN_P_BF16_S32>(a, st);
+        rc = s16 ? launch_f2ring<NHh, CGNN_P_BF16_S16>(a, st)                                               \
+                 : (f16 ? launch_f2ring<NHh, CGNN_P_F16_S32>(a, st) : launch_f2ring<NHh, CGNN_P_BF16_S32>(a, st));
     CGNN_GO(1) CGNN_GO(2) CGNN_GO(3)
 #undef CGNN_GO
     if (rc == CGNN_OK) *rows_done = n;

@@ -323,6 +323,14 @@ int node_block_x3n16(const MlpDev& m, int precision, const cgnn_linear* w_x, con
     if (T == Tt)                                                                                                      \
         return s16 ? launch<Tt, CGNN_P_BF16_S16, TERMS>(m, ch, b1, x, agg, n, x_out, residual, bd, ps, pd, wsw, wdw, st) \
                    : launch<Tt, CGNN_P_BF16_S32, TERMS>(m, ch, b1, x, agg, n, x_out, residual, bd, ps, pd, wsw, wdw, st);
+    if (fuse && p_format == CGNN_P_F16_S32) {      // cgnn_edge_stream_run_w8's tables: latent 128 only
+        if (T != 4) {
+            set_error("cgnn_node_block: CGNN_P_F16_S32 tables are built for latent 128 (got %d)", 32 * T);
+            return CGNN_ERR_UNSUPPORTED;
+        }
+        return f2 ? launch<4, CGNN_P_F16_S32, 2>(m, ch, b1, x, agg, n, x_out, residual, bd, ps, pd, wsw, wdw, st)
+                  : launch<4, CGNN_P_F16_S32, 3>(m, ch, b1, x, agg, n, x_out, residual, bd, ps, pd, wsw, wdw, st);
+    }
     if (f2) {
         CGNN_GO(1, 2) CGNN_GO(2, 2) CGNN_GO(4, 2)
     } else {

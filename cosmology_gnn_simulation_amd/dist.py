@@ -297,10 +297,10 @@ class ShardedForward:
 
     def _buffers(self, D: int, H: int, dev):
         sh = self.sh
-        key = (D, H, dev, self.model.edge_precision, self.fused)
+        key = (D, H, dev, self.model.edge_precision, self.fused, self.p_fmt)
         if self._bufs is None or self._bufs[0] != key:
             x_all = torch.empty((sh.n_local, D), dtype=torch.float32, device=dev)
-            pdt = self.P["rounds"][0].p_dtype if self.P["rounds"] else torch.float32
+            pdt = ops.p_format_dtype(self.p_fmt) if self.P["rounds"] else torch.float32
             if self.fused:      # every round's tables are kept for the one-launch edge stream (same row stride for both)
                 L = len(self.P["rounds"])
                 ps = torch.empty((L, sh.n_local, H), dtype=pdt, device=dev)
@@ -326,6 +326,14 @@ class ShardedForward:
         # round's Ps / Pd behind; the edge stream then is one launch (cgnn_edge_stream), as on one GPU
         self.image = P["image"]          # cgnn_edge_stream_run's chunk image (None: first-generation kernel or per round)
         self.fused = self.image is not None or m._can_fuse_rounds(P["rounds"], D)
+        # fused mode: the table format the one-launch edge stream of this shard will take (fp16 rows for the
+        # two-waves-per-SIMD kernel, graph_network.stream_table_format); per round: each round's own
+        self.p_fmt = P["rounds"][0].p_format if P["rounds"] else _lib.P_F32
+        if self.fused and self.image is not None:
+            from .graph_network import stream_table_format
+            attr0 = sh.edge_attr if bool(self.image.enc_in) else None
+            _, kern = m._edge_stream_plan(P, sh.k, sh.src_local.numel(), attr0)
+            self.p_fmt = stream_table_format(P["rounds"], kern, int(getattr(m, "edge_stream_lag", 0)))
         self.x_all, self.ps, self.pd, self.agg, self.x_alt = self._buffers(D, H, sh.x_feat.device)
         ops.mlp_rows(P["enc_node"], sh.x_feat, out=self.x_all[:sh.n_owned])
         self._projected = False
@@ -389,11 +397,11 @@ class ShardedForward:
         no, ni, k = sh.n_owned, sh.n_interior, sh.k
         a, b = {"all": (0, no), "interior": (0, ni), "boundary": (ni, no)}[part]
         if part != "interior" and sh.n_ghost:
-            ops.project_nodes(p.ws, None, self.x_all[no:], self.ps[i][no:], None, p.p_format)
+            ops.project_nodes(p.ws, None, self.x_all[no:], self.ps[i][no:], None, self.p_fmt)
         if b > a:
             x_in = self.x_all[a:b]
             if i == 0:
-                ops.project_nodes(p.ws, p.wd, x_in, self.ps[0][a:b], self.pd[0][a:b], p.p_format)
+                ops.project_nodes(p.ws, p.wd, x_in, self.ps[0][a:b], self.pd[0][a:b], self.p_fmt)
             src_part = self._src_part(a, b)
             ops.aggregate(self.x_all, src_part, None, b - a, k, (b - a) * k, self.agg[a:b],
                           plan=ops.AggregatePlan.of(src_part, b - a, k, self.x_all.shape[1]))
@@ -402,7 +410,7 @@ class ShardedForward:
                 q = rounds[i + 1]
                 fused_ok = p.node.precision in _lib.N16_NODE and q.ws_fused.precision == _lib.BF16_N16
                 nxt = (q.ws_fused if fused_ok else q.ws, q.wd_fused if fused_ok else q.wd, self.ps[i + 1][a:b],
-                       self.pd[i + 1][a:b], q.p_format)
+                       self.pd[i + 1][a:b], self.p_fmt)
             ops.node_block(p.node, p.wx, p.wa, x_in, self.agg[a:b], self.x_alt[a:b], True, nxt)
         if part != "interior":
             self.x_all, self.x_alt = self.x_alt, self.x_all

@@ -16,8 +16,17 @@ is untouched):
     latents* and the updated edge latents never reach the nodes.
     ``"edge"`` aggregates the updated edge latents (the Interaction Network the
     reference's docstrings describe).
-``edge_precision`` / ``node_precision``  ``"fp32"`` (exact f32 MFMA, default) or
-    ``"bf16"`` (bf16 MFMA operands, f32 accumulation, f32 LayerNorm/residual).
+``edge_precision``  ``"fp32"`` (exact f32 MFMA, default), ``"bf16"`` (bf16 MFMA operands, f32
+    accumulation, f32 LayerNorm / residual: BASELINE cfg3-5), or ``"fp16x2"`` (f32 accuracy from two fp16
+    terms per operand on the fp16 matrix cores, latent = hidden = 128: BASELINE cfg2; ``"fp32x3"`` is accepted
+    as a synonym -- there is no three-bf16-term edge kernel -- and other shapes take exact f32).
+``node_precision``  ``"fp32"`` (default), ``"bf16"``, or one of the two f32 emulations on the matrix cores that
+    hold the 1e-5 gate: ``"fp16x2"`` (two fp16 terms, three products; |activation| < 65504, else the row
+    comes back NaN) and ``"fp32x3"`` (three bf16 terms, six products, f32 range).  DESIGN.md section 5.
+``fuse_rounds`` / ``edge_stream_kernel``  x_j mode: all rounds of the edge stream in one launch
+    (``"tile32w"`` two waves per SIMD, ``"tile32"`` one wave per SIMD, ``"tile16"`` first generation).
+``train_precision`` / ``train_edge_stream``  arithmetic of the differentiable forward + backward
+    (``"fp32"`` / ``"fp32x3"``) and whether a training step also runs the (gradient-free) edge stream.
 """
 from __future__ import annotations
 
@@ -310,6 +319,17 @@ def _run_round(p: _PackedProcessor, x: torch.Tensor, e: torch.Tensor, src, dst, 
     return x_new, e_new, nxt is not None
 
 
+def stream_table_format(rounds, stream_kernel: Optional[str], stream_lag: int = 0) -> int:
+    """``cgnn_ptable`` format of the Ps / Pd tables the node stream leaves for the one-launch edge stream.
+    ``cgnn_edge_stream_run_w8`` (``"tile32w"``, lag 0) adds ``Ps[src] + Pd[dst]`` on the vector pipe when the tables are fp16
+    (``CGNN_P_F16_S32``: the same order and projection arithmetic, the f32 sums rounded to 11 significand bits instead of
+    bf16's 8): 16 fewer MFMAs per tile and round than the selector MFMAs that bf16 rows need."""
+    fmt = rounds[0].p_format
+    if stream_kernel == "tile32w" and stream_lag == 0 and fmt == _lib.P_BF16_S32:
+        fmt = _lib.P_F16_S32
+    return fmt
+
+
 def _run_rounds_fused(rounds, x: torch.Tensor, e, src, dst, fixed_k: int, agg: Optional[torch.Tensor],
                       encoder=None, edge_attr: Optional[torch.Tensor] = None, image=None, keep: Optional[dict] = None,
                       stream_kernel: str = "tile32", stream_lag: int = 0):
@@ -319,9 +339,10 @@ def _run_rounds_fused(rounds, x: torch.Tensor, e, src, dst, fixed_k: int, agg: O
     registers.  Same kernels' arithmetic as the round-by-round path: results are bit-identical."""
     n, L = x.shape[0], len(rounds)
     H = rounds[0].ws.out_dim
-    ps_all = torch.empty((L, n, H), dtype=torch.bfloat16, device=x.device)
-    pd_all = torch.empty((L, n, H), dtype=torch.bfloat16, device=x.device)
-    fmt = rounds[0].p_format
+    fmt = stream_table_format(rounds, stream_kernel if image is not None else None, stream_lag)
+    pdt = ops.p_format_dtype(fmt)
+    ps_all = torch.empty((L, n, H), dtype=pdt, device=x.device)
+    pd_all = torch.empty((L, n, H), dtype=pdt, device=x.device)
     ops.project_nodes(rounds[0].ws, rounds[0].wd, x, ps_all[0], pd_all[0], fmt)
     plan = ops.AggregatePlan.of(src, n, fixed_k, x.shape[1])       # built once per graph, cached on its sender list
     for i, p in enumerate(rounds):

@@ -224,6 +224,11 @@ def p_table_format(edge_mlp_precision) -> int:
             _lib.F16X2_N16: _lib.P_F32, _lib.F16X2: _lib.P_F32}[_prec(edge_mlp_precision)]
 
 
+def p_format_dtype(p_format: int) -> torch.dtype:
+    """torch element type of a ``cgnn_ptable`` format."""
+    return {_lib.P_F32: torch.float32, _lib.P_F16_S32: torch.float16}.get(p_format, torch.bfloat16)
+
+
 def p_table_dtype(edge_mlp_precision) -> torch.dtype:
     """Element type of the Ps/Pd gather tables (engine-internal layout, see include/cgnn.h)."""
     return torch.float32 if _prec(edge_mlp_precision) in (F32, _lib.F16X2_N16, _lib.F16X2) else torch.bfloat16
@@ -239,7 +244,7 @@ def project_nodes(ws: Optional[PackedLinear], wd: Optional[PackedLinear], x: tor
     ref = ws if ws is not None else wd
     if p_format is None:
         p_format = p_table_format(ref.precision)
-    pdt = torch.float32 if p_format == _lib.P_F32 else torch.bfloat16
+    pdt = p_format_dtype(p_format)
     if ws is not None and ps is None:
         ps = torch.empty((n, ws.out_dim), dtype=pdt, device=x.device)
     if wd is not None and pd is None:
@@ -389,7 +394,9 @@ def edge_stream_run(image: StreamImage, ps_all: torch.Tensor, pd_all: torch.Tens
                     edge_attr: Optional[torch.Tensor] = None, kernel: str = "tile32", lag: int = 1,
                     fixed_k: int = 0) -> TiledRows:
     """All residual edge updates of ``image`` in one launch.  ``ps_all`` / ``pd_all``: ``[rounds, N, latent]`` bf16
-    tables in ``CGNN_P_BF16_S32`` format.  When the image starts with the encoder the initial latents come from
+    tables in ``CGNN_P_BF16_S32`` format -- or, ``"tile32w"`` with ``lag = 0`` only, float16 tables in ``CGNN_P_F16_S32``
+    format (the same order; the kernel then adds ``Ps[src] + Pd[dst]`` on the vector pipe instead of through selector
+    MFMAs: what the model runs).  When the image starts with the encoder the initial latents come from
     ``edge_attr`` and ``e_in`` is ignored.  ``kernel``: ``"tile32"`` = ``cgnn_edge_stream_run`` (one wave per SIMD, two
     tiles per wave), ``"tile32w"`` = ``cgnn_edge_stream_run_w8`` (two waves per SIMD, one tile each; ``lag`` and
     ``fixed_k`` as in include/cgnn.h: the graph's fixed in-degree, ``dst[e] == e // fixed_k``; see
@@ -411,11 +418,15 @@ def edge_stream_run(image: StreamImage, ps_all: torch.Tensor, pd_all: torch.Tens
         raise CgnnError("edge_stream_run: e_in must be the TiledRows edge latents")
     if e_out is None:
         e_out = TiledRows(ne, latent, src.device) if e_in is None else e_in.empty_like()
+    pdt = ps_all.dtype
+    if pdt == torch.float16 and (kernel != "tile32w" or lag != 0):
+        raise CgnnError("edge_stream_run: float16 (CGNN_P_F16_S32) tables are for kernel='tile32w' with lag=0")
     for t, name in ((ps_all, "ps_all"), (pd_all, "pd_all")):
         require_device(t, name)
-        if t.dtype != torch.bfloat16 or not t.is_contiguous() or t.dim() != 3 or t.shape[0] != image.rounds or \
-                t.shape[2] != latent:
-            raise CgnnError(f"edge_stream_run: {name} must be a contiguous bfloat16 [rounds, N, latent] table")
+        if t.dtype != pdt or pdt not in (torch.bfloat16, torch.float16) or not t.is_contiguous() or t.dim() != 3 or \
+                t.shape[0] != image.rounds or t.shape[2] != latent:
+            raise CgnnError(f"edge_stream_run: {name} must be a contiguous bfloat16 (or, tile32w, float16) "
+                            f"[rounds, N, latent] table")
     if dst.numel() != ne or e_out.n != ne or e_out.width != latent:
         raise CgnnError("edge_stream_run: src/dst/e_out do not match the edge latents")
     args = (image.buf.data_ptr(), image.buf.numel(), latent, image.nh, image.rounds, image.enc_in, ps_all.data_ptr(),
@@ -424,8 +435,9 @@ def edge_stream_run(image: StreamImage, ps_all: torch.Tensor, pd_all: torch.Tens
             edge_attr.stride(0) if edge_attr is not None else 0)
     with _timed("edge_stream", src.device):
         if kernel == "tile32w":
-            check(_lib.load().cgnn_edge_stream_run_w8(*args, int(lag), int(fixed_k), stream_ptr(src.device)),
-                  "cgnn_edge_stream_run_w8")
+            check(_lib.load().cgnn_edge_stream_run_w8(*args, int(lag), int(fixed_k),
+                                                      _lib.P_F16_S32 if pdt == torch.float16 else _lib.P_BF16_S32,
+                                                      stream_ptr(src.device)), "cgnn_edge_stream_run_w8")
         else:
             check(_lib.load().cgnn_edge_stream_run(*args, stream_ptr(src.device)), "cgnn_edge_stream_run")
     return e_out
@@ -528,7 +540,7 @@ def node_block(mlp: PackedMLP, w_x: PackedLinear, w_agg: PackedLinear, x: torch.
     if next_projection is not None:
         ws, wd, ps, pd, p_format = next_projection
         s1, s2 = ws.struct(), wd.struct()
-        pdt = torch.float32 if p_format == _lib.P_F32 else torch.bfloat16
+        pdt = p_format_dtype(p_format)
         for t in (ps, pd):
             require_device(t, "projection table")
             if t.dtype != pdt or not t.is_contiguous() or t.shape != (n, ws.out_dim):

@@ -76,8 +76,12 @@ typedef enum {
  *   CGNN_P_BF16_S32  bf16, f = 32t+8g+4h+c at h*(H/2) + (4t+g)*4 + c      (mlp precision CGNN_BF16)
  *   CGNN_P_BF16_S16  bf16, f = 16O+4q+i    at (4*(O/2) + q)*8 + 4*(O%2) + i   (mlp precision CGNN_BF16_N16: the
  *                    16-edge kernel's MFMA B-operand order, so the rows enter the accumulators through the matrix pipe)
+ *   CGNN_P_F16_S32   IEEE fp16 in CGNN_P_BF16_S32's order (projection weights CGNN_BF16 / CGNN_BF16_N16, the f32 sums
+ *                    rounded to fp16: 11 significand bits instead of 8, |value| < 65520): the table format of
+ *                    cgnn_edge_stream_run_w8, which adds Ps[src] + Pd[dst] on the vector pipe with one v_fma_mix_f32 per
+ *                    value (fp16 widens for free there; bf16 rows need four selector MFMAs per row tile instead)
  * i.e. each lane of the consuming kernel reads one contiguous run. */
-typedef enum { CGNN_P_F32 = 0, CGNN_P_BF16_S32 = 1, CGNN_P_BF16_S16 = 2 } cgnn_ptable;
+typedef enum { CGNN_P_F32 = 0, CGNN_P_BF16_S32 = 1, CGNN_P_BF16_S16 = 2, CGNN_P_F16_S32 = 3 } cgnn_ptable;
 
 /*
  * Memory layout of an [n, width] float32 matrix.
@@ -270,6 +274,9 @@ int cgnn_edge_stream_run(const void* image, size_t image_bytes, int32_t latent, 
  * (cgnn_edge_stream_w8_supported); every other shape or edge list: cgnn_edge_stream_run.
  * lag = 1: the second wave of every SIMD runs one layer behind the first (their LayerNorms never coincide), 0: in step;
  * results do not depend on lag.
+ * p_format: CGNN_P_F16_S32 (fp16 tables: Ps[src] + Pd[dst] is one v_fma_mix_f32 per value on the vector pipe, most of them
+ * under the first layer's MFMAs; lag = 0 only) or CGNN_P_BF16_S32 (the tables of cgnn_edge_stream_run: the rows enter the
+ * accumulators through four selector MFMAs per row tile, 14 % more matrix work per round).
  * Its image differs from cgnn_edge_stream_run's in one thing: every bias sits one chunk early (the kernel reads a layer's
  * bias while the previous layer still computes); cgnn_edge_stream_image_build_w8 builds it (same arguments and size). */
 int cgnn_edge_stream_w8_supported(int32_t latent, int32_t num_hidden_layers, int32_t fixed_k);
@@ -279,7 +286,7 @@ int cgnn_edge_stream_run_w8(const void* image, size_t image_bytes, int32_t laten
                             int32_t num_rounds, int32_t enc_in_dim, const void* ps_all, const void* pd_all,
                             int64_t round_stride, const int32_t* src, const int32_t* dst, int64_t num_edges,
                             const float* e_in, float* e_out, const float* edge_attr, int32_t ld_attr, int32_t lag,
-                            int32_t fixed_k, void* stream);
+                            int32_t fixed_k, int32_t p_format, void* stream);
 
 /* ---- backward of a row-wise MLP (+LayerNorm): the node stream of train.py:263 ------------------------
  * In reference-faithful mode only the node path carries gradient (the edge models' parameters get
