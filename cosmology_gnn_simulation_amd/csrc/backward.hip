@@ -501,6 +501,8 @@ int cgnn_mlp_backward(const cgnn_mlp* fwd, const cgnn_linear* fwd_part2, const c
     // square models hidden == latent in {32, 64, 128, 256}: node block (two inputs), encoder (narrow input), decoder
 #define CGNN_BWD_T(Tt) CGNN_BWD(Tt, Tt, Tt, Tt) CGNN_BWD(1, 0, Tt, Tt) CGNN_BWD(Tt, 0, Tt, 1)
     CGNN_BWD_T(1) CGNN_BWD_T(2) CGNN_BWD_T(4) CGNN_BWD_T(8)
+    // encoders with 33 .. 64 input features (reference config.py:18 --window_size > 8: 3 (W - 1) + W node features, 37 at W = 10)
+    CGNN_BWD(2, 0, 2, 2) CGNN_BWD(2, 0, 4, 4) CGNN_BWD(2, 0, 8, 8)
     // mlp_hidden_size != latent_size (reference config.py:19-20 and train.py:165-171 pass them independently): the pairs the
     // forward kernels are compiled for (CGNN_FOR_EACH_PAIR): hidden 128 with latent 64 or 256
 #define CGNN_BWD_M(Lt) CGNN_BWD(Lt, Lt, 4, Lt) CGNN_BWD(1, 0, 4, Lt) CGNN_BWD(Lt, 0, 4, 1)

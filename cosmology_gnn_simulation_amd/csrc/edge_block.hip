@@ -146,11 +146,7 @@ __global__ __launch_bounds__(BLOCK) void edge_block_n16_kernel(
         const int64_t e = tile * 16 + c;
         const int64_t ec = e < num_edges ? e : num_edges - 1;
         const int64_t s = src[ec], d = dst[ec];
-#ifdef CGNN_ABLATE_STREAM   // developer ablation: same instructions, the tile stream stays in L2
-        const int64_t tbase = ((tile & 255) >> 1) * (32 * D) + n16_lane_offset(c, q, (int)(tile & 1));
-#else
         const int64_t tbase = (tile >> 1) * (32 * D) + n16_lane_offset(c, q, (int)(tile & 1));
-#endif
         f32x4 ev[DO];
 #pragma unroll
         for (int o = 0; o < DO; ++o)   // streamed once: non-temporal, so that the P-table rows keep their L2 lines
@@ -159,14 +155,6 @@ __global__ __launch_bounds__(BLOCK) void edge_block_n16_kernel(
         load_p16_operand<HT>(pso, ps, s, q);
         load_p16_operand<HT>(pdo, pd, d, q);
         f32x4 out[DO];
-#ifdef CGNN_ABLATE_REPEAT   // developer ablation: REPEAT rounds on the tile in registers (compute rate without the stream)
-#pragma nounroll
-        for (int rep = 0; rep < CGNN_ABLATE_REPEAT; ++rep) {
-        if (rep > 0) {
-#pragma unroll
-            for (int o = 0; o < DO; ++o) ev[o] += out[o];
-        }
-#endif
         bf16x8 oph[HT];
         {
             bf16x8 op[DT];
@@ -185,9 +173,6 @@ __global__ __launch_bounds__(BLOCK) void edge_block_n16_kernel(
         fill16<DO>(out, VecSel<true>::bias(m, m.nh), q);
         dense16<HT, DO, CGNN_EDGE_N16_GS>(out, oph, WSel<CGNN_BF16, true>::get(m, m.nh), lane);
         layer_norm16<DO>(out, VecSel<true>::gamma(m), VecSel<true>::beta(m), q);
-#ifdef CGNN_ABLATE_REPEAT
-        }
-#endif
         if (e_upd != nullptr) {
 #pragma unroll
             for (int o = 0; o < DO; ++o) *reinterpret_cast<f32x4*>(e_upd + tbase + n16_tile_offset(o)) = out[o];

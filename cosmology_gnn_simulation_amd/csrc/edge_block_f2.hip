@@ -200,9 +200,7 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void edge_block_f2ring_kernel(F2Edg
         }
         F2R_STAMP(5);
         fold16f2<OT>(c0, c1);
-#ifndef CGNN_F2R_ABL_LN
         layer_norm16<OT>(c0, vec + (NH + 1) * D, vec + (NH + 2) * D, q);
-#endif
         F2R_STAMP(6);
         if (valid) {   // always true in the full-step instantiation
             const int64_t tb = tile_offset(ht);

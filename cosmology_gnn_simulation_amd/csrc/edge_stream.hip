@@ -162,9 +162,6 @@ struct LayerRing {
         return n;
     }
     __device__ __forceinline__ void piece(int i, int n) const {
-#ifdef CGNN_ABLATE_HALF_DMA     // developer ablation (wrong results): copy only every other piece of each layer
-        if (i & 1) return;
-#endif
         if (i < n) {
             const uint32_t off = (wave + CGNN_STREAM_WAVES * i) * 1024u;
             asm volatile("" ::: "memory");
@@ -321,7 +318,6 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
                     d_n = dst[ec];
                     ring.note(2);
                 }
-#ifndef CGNN_STREAM_NO_EVN
                 if (LAST && more) {
                     if (ENC) {
                         load_attr(at_n, tile_n);
@@ -334,7 +330,6 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
                         ring.note(DO);
                     }
                 }
-#endif
                 CGNN_STAMP(sk++);      // 2: P MFMAs issued
                 // The P registers are free again: the rows of the next round (or of the next tile's round 0) and this
                 // wave's pieces of the layer two ahead are requested BETWEEN the MFMA groups below, pieces first.
@@ -437,7 +432,6 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
             ring.note(DO);
         }
         if (more) {
-#ifndef CGNN_STREAM_NO_EVN
             if (ENC) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) at[j] = at_n[j];
@@ -445,12 +439,6 @@ __global__ __launch_bounds__(CGNN_STREAM_BLOCK) void edge_stream_n16_kernel(
 #pragma unroll
                 for (int o = 0; o < DO; ++o) ev[o] = ev_n[o];
             }
-#else       // (developer variant for smaller register budgets: the next tile's latents are fetched only now)
-#pragma unroll
-            for (int o = 0; o < DO; ++o)
-                ev[o] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(e_in + tbase_n + n16_tile_offset(o)));
-            ring.note(DO);
-#endif
             tile = tile_n;
             tbase = tbase_n;
             valid = valid_n;

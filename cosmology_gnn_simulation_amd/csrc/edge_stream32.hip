@@ -57,19 +57,16 @@ struct Ring32 {
     // (always the slot of the step just left), which keeps every wait count a constant and the loop free of branches;
     // the kernel drains them before it ends.
     __device__ __forceinline__ void piece(int i) {
-#ifdef CGNN_S32_ABLATE_DMA     // developer timing build (wrong results): the ring is never refilled
-        if (primed) return;
-#endif
         const unsigned off = (unsigned)(wave + CGNN_S32_WAVES * i) * 1024u;
         char* dst = cgnn_smem + (unsigned)dma_slot * G::STRIDE + off;
         asm volatile("" ::: "memory");
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(CGNN_S32_GLOBAL_DMA)
+#if defined(__HIP_DEVICE_COMPILE__)
         // Buffer form of the LDS-DMA instruction (buffer_load_dwordx4 ... offen lds): descriptor of the image + the
         // piece's byte offset as a SCALAR + one constant lane offset, so a piece costs no vector instruction.  The
         // global form needs a 64-bit vector add per piece (27 pieces per pass): 0.3 ms of this kernel (A/B on one box:
         // 20.71 -> 20.39 ms).  An earlier attempt at a scalar base through inline asm (s_mov m0 + global_load_lds with an
         // SGPR pair) was 0.1-0.5 ms SLOWER: an asm statement fences the scheduler, this builtin does not.
-        // (CGNN_S32_GLOBAL_DMA keeps the old form for A/B timing; the host pass of hipcc does not know the buffer builtin.)
+        // (The host pass of hipcc does not know the buffer builtin: it sees the global form below, which never runs.)
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(image), 0, (int)((unsigned)count * G::STRIDE), 0x00020000);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsVoidPtrG)dst, 16, (unsigned)lane * 16u,
@@ -103,9 +100,7 @@ struct Ring32 {
     template <int EXTRA>
     __device__ __forceinline__ void sync_next() {
         wait_next_chunk<EXTRA>();
-#ifndef CGNN_S32_ABLATE_BARRIER
         __builtin_amdgcn_s_barrier();
-#endif
         asm volatile("" ::: "memory");
     }
     __device__ __forceinline__ void advance() { slot = (slot + 1) & (CGNN_S32_SLOTS - 1); }
@@ -172,30 +167,14 @@ __device__ __forceinline__ void lds_wait2i(u32x4& a, u32x4& b) {
 // acc[o] += W[32 o .. 32 o + 31, :] . in ; fragment m = o * KS + ks (1 KiB, lane-linear) at addr + m * 1024.  The LDS
 // reads and their counted waits are written by hand (hipcc waits lgkmcnt(0) before every group otherwise); PD groups
 // of four fragments are in flight ahead of the MFMAs.  Rows are finished one after the other (o outermost).
-#ifdef CGNN_S32_DUMMY_FILL
-template <int N>
-__device__ __forceinline__ void dummy_fill(float& a, float& b, float& c, float& d) {
-    if constexpr (N > 0) {
-        asm volatile("v_add_f32 %0, %0, %0" : "+v"(a));
-        dummy_fill<N - 1>(b, c, d, a);
-    }
-}
-#endif
 template <int NROW, int KS, class Fill>
 __device__ __forceinline__ void wblock32(f32x16 (&acc)[NROW], const bf16x8 (&in)[KS], unsigned addr, const Fill& fill) {
-#ifdef CGNN_S32_DUMMY_FILL
-    float dummy0 = 1.f, dummy1 = 2.f, dummy2 = 3.f, dummy3 = 4.f;
-#endif
     typedef WBlock<NROW, KS> WB;
     constexpr int M = WB::M, GS = WB::GS, NG = WB::NG, PD = WB::PD, NBUF = PD + 1;
     static_assert(M % GS == 0 && (GS == 4 || GS == 2 || GS == 1), "groups of four (two, one) fragments");
     // issue index t -> fragment: rows in pairs, the two rows of a pair alternating (consecutive MFMAs then write
     // different accumulators), or plainly row after row
-#ifdef CGNN_S32_ROWPAIR
-#define CGNN_S32_FRAG(t) ((NROW % 2 == 0) ? ((((t) / (2 * KS)) * 2 + (t) % 2) * KS + ((t) / 2) % KS) : (t))
-#else
 #define CGNN_S32_FRAG(t) (t)
-#endif
     const unsigned a = addr + (unsigned)(threadIdx.x & 63) * 16u;
     u32x4 buf[NBUF][GS];
     static_for_each([&](auto pc) __attribute__((always_inline)) {
@@ -224,9 +203,6 @@ __device__ __forceinline__ void wblock32(f32x16 (&acc)[NROW], const bf16x8 (&in)
                                                              0);
             if constexpr (g + PD < NG) buf[(g + PD) % NBUF][j] = lds_read_b128_acc<CGNN_S32_FRAG((g + PD) * GS + j) * 1024>(a);
             fill.template run<m>();
-#ifdef CGNN_S32_DUMMY_FILL      // developer timing build: N independent vector instructions behind every MFMA
-            dummy_fill<CGNN_S32_DUMMY_FILL>(dummy0, dummy1, dummy2, dummy3);
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }, std::make_integer_sequence<int, GS>{});
     }, std::make_integer_sequence<int, NG>{});
@@ -281,11 +257,7 @@ __device__ __forceinline__ void wblock32p(f32x16 (&acc)[NROW], const bf16x8 (&in
 template <int IDX>
 __device__ __forceinline__ bf16x8 p32_load(unsigned off, const __bf16* table) {     // off = (row * H + h * (H / 2)) * 2
     u32x4 r;
-#ifndef CGNN_S32_ABLATE_P
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(r) : "v"(off), "s"(table), "n"(IDX * 16));
-#else
-    r = u32x4{0u, 0u, 0u, 0u};
-#endif
     return __builtin_bit_cast(bf16x8, r);
 }
 template <int DT>
@@ -314,16 +286,6 @@ __device__ __forceinline__ void pack32_slice(Tile32<DT>& X) {
 }
 template <bool RELU, int DT, int S0, int S1>
 __device__ __forceinline__ void pack32_run(Tile32<DT>& X) {
-#ifdef CGNN_S32_ABLATE_PACK     // (timing build: keep the layer's MFMAs alive)
-    if constexpr (S0 == 0 && S1 > 0) {
-#pragma unroll
-        for (int t = 0; t < DT; ++t) {
-            const float keep_alive = X.acc[t][0];
-            asm volatile("" ::"v"(keep_alive));
-        }
-    }
-    return;
-#endif
     static_for_each([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value + S0;
         if constexpr (u < S1) pack32_slice<RELU, DT, u>(X);
@@ -399,14 +361,9 @@ __device__ __forceinline__ void ln32_slice(Tile32<DT>& X, LnVec32& V, unsigned g
 #pragma unroll
         for (int t = 1; t < DT; ++t) q += X.part[t];
         X.rstd = __builtin_amdgcn_rsqf(half_swap_sum(q) * (1.0f / D) + 1e-5f);
-#ifndef CGNN_S32_ABLATE_LNVEC
         ln32_vec_read<0>(V.g[0][0], V.g[0][1], V.b[0][0], V.b[0][1], ga, ba);      // vectors of the first affine slice
-#else
-        V.g[0][0] = V.g[0][1] = V.b[0][0] = V.b[0][1] = V.g[1][0] = V.g[1][1] = V.b[1][0] = V.b[1][1] = u32x4{0x3f800000u, 0x3f800000u, 0x3f800000u, 0x3f800000u};
-#endif
     } else {
         constexpr int k = U - LN::AFF0, t = k >> 1, sx = k & 1, cur = k & 1, nxt = cur ^ 1;
-#ifndef CGNN_S32_ABLATE_LNVEC
         if constexpr (k + 1 < LN::NAFF) {
             constexpr int t1 = (k + 1) >> 1, s1 = (k + 1) & 1;
             ln32_vec_read<(32 * t1 + 16 * s1) * 4>(V.g[nxt][0], V.g[nxt][1], V.b[nxt][0], V.b[nxt][1], ga, ba);
@@ -414,7 +371,6 @@ __device__ __forceinline__ void ln32_slice(Tile32<DT>& X, LnVec32& V, unsigned g
         } else {
             ln32_vec_wait<NEWER>(V.g[cur][0], V.g[cur][1], V.b[cur][0], V.b[cur][1]);
         }
-#endif
         const f32x2 r2 = {X.rstd, X.rstd};
         f32x2 e[4];
 #pragma unroll
@@ -424,24 +380,20 @@ __device__ __forceinline__ void ln32_slice(Tile32<DT>& X, LnVec32& V, unsigned g
             constexpr int i0 = 8 * sx;
             const int i = i0 + 4 * gg;
             f32x2 base[2] = {f32x2{bt[0], bt[1]}, f32x2{bt[2], bt[3]}};
-#ifndef CGNN_S32_ABLATE_LNACC
             if (RES) {
                 float p0, p1, p2, p3;
                 acc_get4(p0, p1, p2, p3, X.evp[t][i], X.evp[t][i + 1], X.evp[t][i + 2], X.evp[t][i + 3]);
                 base[0] += f32x2{p0, p1};
                 base[1] += f32x2{p2, p3};
             }
-#endif
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const f32x2 w = f32x2{gm[2 * c], gm[2 * c + 1]} * r2;
                 const f32x2 d = {X.acc[t][i + 2 * c], X.acc[t][i + 2 * c + 1]};
                 e[2 * gg + c] = __builtin_elementwise_fma(d, w, base[c]);
             }
-#ifndef CGNN_S32_ABLATE_LNACC
             acc_put4(X.evp[t][i], X.evp[t][i + 1], X.evp[t][i + 2], X.evp[t][i + 3], e[2 * gg][0], e[2 * gg][1],
                      e[2 * gg + 1][0], e[2 * gg + 1][1]);
-#endif
         }
         u32x4 v;
 #pragma unroll
@@ -452,16 +404,6 @@ __device__ __forceinline__ void ln32_slice(Tile32<DT>& X, LnVec32& V, unsigned g
 // slices [S0, S1); NEWER0 applies to the first of them (see ln32_slice), the others follow it directly
 template <bool RES, int DT, int S0, int S1, int NEWER0>
 __device__ __forceinline__ void ln32_run(Tile32<DT>& X, LnVec32& V, unsigned ga, unsigned ba) {
-#ifdef CGNN_S32_ABLATE_LN       // (timing build: keep the layer's MFMAs alive)
-    if constexpr (S0 == 0 && S1 > 0) {
-#pragma unroll
-        for (int t = 0; t < DT; ++t) {
-            const float keep_alive = X.acc[t][0];
-            asm volatile("" ::"v"(keep_alive));
-        }
-    }
-    return;
-#endif
     static_for_each([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value + S0;
         if constexpr (u < S1) ln32_slice<RES, DT, u, (u == S0 ? NEWER0 : 0)>(X, V, ga, ba);
@@ -476,11 +418,7 @@ __device__ __forceinline__ void bias_rows32(f32x16 (&acc)[DT], unsigned vec_addr
     for (int t = T0; t < T1; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-#ifdef CGNN_S32_ABLATE_BIAS
-            const f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#else
             const f32x4 v = *(LdsVec4Ptr)(b + 32 * t + 8 * g + 4 * h);
-#endif
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[t][4 * g + c] = v[c];
         }
@@ -543,11 +481,7 @@ __global__ __launch_bounds__(CGNN_S32_BLOCK, 1) void edge_stream32_kernel(
     Ring32<G> ring(a.image, steps_per_pair, wave, lane);
     ring.prime();
     // latent 128: the LDS fragment pipeline runs across block boundaries (wblock32p); its buffers live here
-#ifdef CGNN_S32_NO_XBLOCK     // developer A/B: every block starts its own fragment pipeline
-    constexpr bool XBLOCK = false;
-#else
     constexpr bool XBLOCK = DT == 4;
-#endif
     WBuf32 wbuf;
     if constexpr (XBLOCK) wprefetch32(wbuf, ring.base());
 #define CGNN_S32_WB(KSx, ACC, IN, BASE, NEXT, ...)                                  \

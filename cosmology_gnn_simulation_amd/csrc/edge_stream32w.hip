@@ -36,63 +36,7 @@ namespace cgnn {
 #define CGNN_W8_BLOCK (CGNN_W8_WAVES * 64)
 #define CGNN_W8_SLOTS 3
 #define CGNN_IC(x) std::integral_constant<int, (x)> {}
-#ifndef CGNN_W8_GS
-#define CGNN_W8_GS 2       // LDS weight fragments per group (2 with two groups in flight: 17.78 against 17.98 ms with 4 / 1,
-                           // same box; 4 / 2 and an issue priority around every MFMA measured no better)
-#endif
-#ifndef CGNN_W8_LN_EARLY
-#define CGNN_W8_LN_EARLY 0    // LayerNorm affine slices (of 2 * latent / 32) done in the output layer's own step, before the barrier
-#endif
-// MFMA slots (within the next row tile's eight) that carry a finished row tile's pack halves / LayerNorm sums.  One slot
-// later than "as early as possible" (1, 3 / 2, 4): the vector instructions then read accumulators whose last MFMA is one
-// more MFMA old and issue without the wait (hipcc had padded them with s_nop 8 / 11): -1.5 % in same-box A/Bs.  (Holding the
-// second-to-last row tile's share back for the end of the block, to have work under the last MFMA's latency: +0.3 .. 1.2 %.)
-#ifndef CGNN_W8_PK0
-#define CGNN_W8_PK0 2
-#define CGNN_W8_PK1 4
-#endif
-#ifndef CGNN_W8_SM0
-#define CGNN_W8_SM0 4
-#define CGNN_W8_SM1 6
-#endif
-#ifndef CGNN_W8_PD
-#define CGNN_W8_PD 2       // groups in flight ahead of the MFMAs
-#endif
-#ifndef CGNN_W8_PF16_INBLK
-#define CGNN_W8_PF16_INBLK 1
-#endif
-#ifndef CGNN_W8_ADDP0     // slots (within a row tile's eight) that carry the next row tile's P sums, eight values each
-#define CGNN_W8_ADDP0 5
-#define CGNN_W8_ADDP1 6
-#endif
-#ifndef CGNN_W8_LN_PHASED
-#define CGNN_W8_LN_PHASED 1
-#endif
-#ifndef CGNN_W8_REQ_EARLY
-#define CGNN_W8_REQ_EARLY 1   // a round's layer-0 fragments requested before its selector MFMAs
-#endif
-#ifndef CGNN_W8_CARRY
-#define CGNN_W8_CARRY 1    // LAG 0: the ring's barrier vouches for chunk g + 2 (not g + 1), the LDS fragment pipeline runs across steps
-#endif
-
-#ifdef CGNN_W8_STAMPS   // developer build: per-phase cycle sums (s_memtime into scalar registers, no memory traffic inside the
-                        // loop) of one workgroup's waves, printed by the launcher
-__device__ unsigned long long cgnn_w8_stamps[8 * 32];
-struct W8Timer {
-    unsigned long long sum[20], prev;
-};
-#define CGNN_W8_STAMP(k)                                                                 \
-    {                                                                                    \
-        unsigned long long t_;                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                               \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
-        __builtin_amdgcn_sched_barrier(0);                                               \
-        tm.sum[k] += t_ - tm.prev;                                                       \
-        tm.prev = t_;                                                                    \
-    }
-#else
-#define CGNN_W8_STAMP(k)
-#endif
+#include "w8_dev.hpp"      // the schedule constants at their shipped values; cycle stamps and timing-only ablations of developer builds
 
 template <int DT>
 struct W8Geom {
@@ -130,9 +74,7 @@ struct RingW {
     int wave, lane;
     int slot;            // of this wave's current step
     int dma_chunk, dma_slot;
-#ifdef CGNN_W8_STAMPS
-    W8Timer tm;
-#endif
+    CGNN_W8_STAMP_MEMBER
     __device__ __forceinline__ RingW(const char* img, int cnt, int w, int l)
         : image(img), count(cnt), wave(w), lane(l), slot(0), dma_chunk(0), dma_slot(0) {}
     __device__ __forceinline__ unsigned lds0() const { return (unsigned)(uintptr_t)(LdsWeightPtr)(cgnn_smem); }
@@ -175,9 +117,7 @@ struct RingW {
     template <int EXTRA, int K0 = 17>
     __device__ __forceinline__ void interval_end() {
         CGNN_W8_STAMP(K0);
-#ifdef CGNN_W8_SLEEP      // developer probe: idle cycles per interval (is the kernel bound by cycles or by the clock it is given?)
-        __builtin_amdgcn_s_sleep(CGNN_W8_SLEEP);
-#endif
+        if constexpr (w8dev::SLEEP > 0) __builtin_amdgcn_s_sleep(w8dev::SLEEP);
         vm_wait_const<(LAG ? 0 : (CGNN_W8_CARRY ? EXTRA : W::NP + EXTRA))>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         CGNN_W8_STAMP(K0 + 1);
@@ -278,9 +218,7 @@ __device__ __forceinline__ void packw_slice(bf16x8 (&out)[2 * DT], const f32x16 
 // acc[t] = bias rows, t in [T0, T1) (plain LDS loads from a chunk's vector block)
 template <int DT, int T0, int T1>
 __device__ __forceinline__ void bias_rowsw(f32x16 (&acc)[DT], unsigned vec_addr, int h) {
-#ifdef CGNN_W8_ABL_BIAS    // developer timing build (wrong results): no bias reads
-    return;
-#endif
+    if constexpr (w8dev::ABL_BIAS) return;
     const LdsVecPtr b = (LdsVecPtr)(uintptr_t)vec_addr;
 #pragma unroll
     for (int t = T0; t < T1; ++t)
@@ -359,48 +297,29 @@ __device__ __forceinline__ void ln_affine_w(const f32x16 (&acc)[DT], f32x16 (&ev
                     bt[nxt][gg] = *(LdsVec4Ptr)(gp + D + 32 * t1 + 8 * (2 * s1 + gg));
                 }
             }
-#ifdef CGNN_W8_ABL_LN       // (developer timing build, wrong results: keeps the MFMAs alive)
-            packw_slice<false, DT, t, s>(in, acc);
+            if constexpr (w8dev::ABL_LN) {      // (timing-only: pack and add, keeps the MFMAs alive)
+                packw_slice<false, DT, t, s>(in, acc);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ev[t][8 * s + i] += acc[t][8 * s + i];
-#else
-#if CGNN_W8_LN_PHASED
-            // the slice's eight values phase by phase (normalise | add beta and the residual | scale by gamma | pack), a
-            // scheduling barrier between the phases: every instruction's inputs are eight instructions old (as one chain
-            // per value hipcc reuses ONE temporary and each fmac waits for the add right in front of it)
-            float nrm[8], bs[8];
+                for (int i = 0; i < 8; ++i) ev[t][8 * s + i] += acc[t][8 * s + i];
+            } else {
+                // the slice's eight values phase by phase (normalise | add beta and the residual | scale by gamma | pack), a
+                // scheduling barrier between the phases: every instruction's inputs are eight instructions old (as one chain
+                // per value hipcc reuses ONE temporary and each fmac waits for the add right in front of it)
+                float nrm[8], bs[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) nrm[i] = __builtin_fmaf(acc[t][8 * s + i], st.rstd, st.nmr);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < 8; ++i) nrm[i] = __builtin_fmaf(acc[t][8 * s + i], st.rstd, st.nmr);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) bs[i] = RES ? bt[cur][i >> 2][i & 3] + ev[t][8 * s + i] : bt[cur][i >> 2][i & 3];
-            __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < 8; ++i) bs[i] = RES ? bt[cur][i >> 2][i & 3] + ev[t][8 * s + i] : bt[cur][i >> 2][i & 3];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ev[t][8 * s + i] = __builtin_fmaf(nrm[i], gm[cur][i >> 2][i & 3], bs[i]);
-            __builtin_amdgcn_sched_barrier(0);
-            u32x4 v;
+                for (int i = 0; i < 8; ++i) ev[t][8 * s + i] = __builtin_fmaf(nrm[i], gm[cur][i >> 2][i & 3], bs[i]);
+                __builtin_amdgcn_sched_barrier(0);
+                u32x4 v;
 #pragma unroll
-            for (int x = 0; x < 4; ++x) v[x] = pack_bf16(ev[t][8 * s + 2 * x], ev[t][8 * s + 2 * x + 1]);
-            in[2 * t + s] = __builtin_bit_cast(bf16x8, v);
-#else
-            u32x4 v;
-#pragma unroll
-            for (int gg = 0; gg < 2; ++gg) {
-                const int g = 2 * s + gg;
-                float e[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float nrm = __builtin_fmaf(acc[t][4 * g + c], st.rstd, st.nmr);
-                    const float base = RES ? bt[cur][gg][c] + ev[t][4 * g + c] : bt[cur][gg][c];
-                    e[c] = __builtin_fmaf(nrm, gm[cur][gg][c], base);
-                    ev[t][4 * g + c] = e[c];
-                }
-                v[2 * gg] = pack_bf16(e[0], e[1]);
-                v[2 * gg + 1] = pack_bf16(e[2], e[3]);
+                for (int x = 0; x < 4; ++x) v[x] = pack_bf16(ev[t][8 * s + 2 * x], ev[t][8 * s + 2 * x + 1]);
+                in[2 * t + s] = __builtin_bit_cast(bf16x8, v);
             }
-            in[2 * t + s] = __builtin_bit_cast(bf16x8, v);
-#endif
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }, std::make_integer_sequence<int, K1 - K0>{});
     }
@@ -410,9 +329,7 @@ __device__ __forceinline__ void ln_affine_w(const f32x16 (&acc)[DT], f32x16 (&ev
 template <int DT, int T0, int T1>
 __device__ __forceinline__ void selp_rows(f32x16 (&acc)[DT], const bf16x8 (&ps)[2 * DT], const bf16x8 (&pd)[2 * DT], bf16x8 sel0,
                                           bf16x8 sel1) {
-#ifdef CGNN_W8_ABL_SEL     // developer timing build (wrong results): no selector MFMAs
-    return;
-#endif
+    if constexpr (w8dev::ABL_SEL) return;
     static_for_each([&](auto tc) __attribute__((always_inline)) {
         constexpr int t = decltype(tc)::value + T0;
         f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -495,11 +412,7 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
         first0 < tr.end ? (int)((tr.end - first0 + tr.stride - 1) / tr.stride) : 0);
     if (iters == 0) return;
     RingW<W, LAG> ring(a.image, steps_per_tile, wave, lane);
-#ifdef CGNN_W8_STAMPS
-    auto& tm = ring.tm;
-    for (int k = 0; k < 20; ++k) tm.sum[k] = 0;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm.prev)::"memory");
-#endif
+    CGNN_W8_STAMP_BEGIN(ring)
     ring.prime();
     if (lagging) ring.idle_interval();
     const bf16x8 sel0 = p32_selector(lane, 0), sel1 = p32_selector(lane, 1);
@@ -583,11 +496,6 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
                 bf16x8, *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)(ps_read ^ ((unsigned)c << 4)));
     };
     // ring pieces of this interval: NP consecutive MFMA slots of the block
-#ifndef CGNN_W8_PIECE_SLOT
-#define CGNN_W8_PIECE_SLOT 16     // first MFMA slot of a 32-MFMA block that issues a ring piece (a piece has the rest of this
-                                  // interval and the whole next one to land; from slot 0: +0.7 % in a same-box A/B, 8: the
-                                  // same as 0, 24: the same as 16 -- the head of a block carries the fragment pipeline's start)
-#endif
     auto pieces_at = [&](auto qc, auto mc) __attribute__((always_inline)) {      // blocks of M MFMAs: slots P0 .. P0 + NP - 1
         constexpr int q = decltype(qc)::value, M = decltype(mc)::value;
         constexpr int P0 = CGNN_W8_PIECE_SLOT + NP <= M ? CGNN_W8_PIECE_SLOT : M - NP;
@@ -866,10 +774,7 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
         }
     }
     if (LAG != 0 && !lagging) ring.idle_interval();
-#ifdef CGNN_W8_STAMPS
-    if (blockIdx.x == 8 && lane == 0)
-        for (int k = 0; k < 20; ++k) cgnn_w8_stamps[wave * 32 + k] = tm.sum[k];
-#endif
+    CGNN_W8_STAMP_END(wave, lane)
     CGNN_S32_VMCNT(0);      // the ring's last refills (unread) must have landed before the workgroup's LDS is released
     __builtin_amdgcn_s_barrier();
 }
@@ -888,38 +793,7 @@ static int launch_w8(const S32Args& a, const __bf16* ps, const __bf16* pd, int64
     const int64_t tiles = (num_edges + 31) / 32;
     const int grid = grid_for_tiles(tiles, 1, CGNN_W8_WAVES);
     kern<<<grid, CGNN_W8_BLOCK, W::LDS, st>>>(a, ps, pd, round_stride, src, dst, num_edges, e_in, e_out, attr, ld_attr, seg_k);
-#ifdef CGNN_W8_STAMPS
-    {
-        static int printed = 0;
-        hipStreamSynchronize(st);
-        if (printed++ == 2) {
-            static unsigned long long hs[8 * 32];
-            hipMemcpyFromSymbol(hs, HIP_SYMBOL(cgnn_w8_stamps), sizeof(hs));
-            // a stamp adds the cycles since the previous stamp to its slot: slot k = the phase that ENDS at stamp k
-            const char* names[20] = {"(gap)", "last: bias, P requests", "last: MFMAs", "last: LayerNorm part, copy", "last: vmcnt wait",
-                                     "last: barrier", "", "", "(gap; tile ends)", "first: LayerNorm rest, Pd", "first: selector MFMAs",
-                                     "first: L0 + pack", "first: vmcnt wait", "first: barrier", "(gap)", "hidden: bias, MFMAs, pack",
-                                     "hidden: vmcnt wait", "hidden: barrier / idle interval", "idle: vmcnt", "idle: barrier"};
-            const double passes = (double)((num_edges + 31) / 32) / (grid * 8.0) * (a.rounds + (enc ? 1 : 0));
-            printf("lag %d: cycles per pass and wave, by phase (sums over the wave's whole run / %.0f passes)\n", LAG, passes);
-            double tot[8] = {0};
-            for (int k = 0; k < 20; ++k) {
-                bool any = false;
-                for (int w = 0; w < 8; ++w) any |= hs[w * 32 + k] != 0;
-                if (!any) continue;
-                printf("  %2d %-28s", k, names[k]);
-                for (int w = 0; w < 8; ++w) {
-                    printf(" %7.0f", hs[w * 32 + k] / passes);
-                    tot[w] += hs[w * 32 + k] / passes;
-                }
-                printf("\n");
-            }
-            printf("     %-28s", "total");
-            for (int w = 0; w < 8; ++w) printf(" %7.0f", tot[w]);
-            printf("\n");
-        }
-    }
-#endif
+    CGNN_W8_STAMP_REPORT(st, num_edges, grid, a.rounds + (enc ? 1 : 0), LAG)
     return check_hip(hipGetLastError(), "cgnn_edge_stream_run_w8 launch");
 }
 

@@ -66,27 +66,10 @@ __device__ unsigned long long cgnn_f2r_stamps[8 * 64];
 #endif
 
 
-// timing-only ablations for scripts/ab (wrong results): -DCGNN_F2R_ABL_DMA / _BARRIER / _SPLIT / _LN / _PMFMA / _PSTORE
-#ifdef CGNN_F2R_ABL_DMA
-#define F2R_ISSUE(C, S)
-#else
 #define F2R_ISSUE(C, S) issue(C, S)
-#endif
-#ifdef CGNN_F2R_ABL_DMA
-#define F2R_CHUNK_WAIT(N)
-#else
 #define F2R_CHUNK_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
-#endif
-#ifdef CGNN_F2R_ABL_BARRIER
-#define F2R_BARRIER()
-#else
 #define F2R_BARRIER() asm volatile("s_barrier" ::: "memory")
-#endif
-#ifdef CGNN_F2R_ABL_SPLIT
-#define F2R_SPLIT(RELU, OP, SRC) asm volatile("" ::"v"(SRC[0][0]), "v"(SRC[OT - 1][3]))
-#else
 #define F2R_SPLIT(RELU, OP, SRC) operand16f2<RELU, KS>(OP, SRC)
-#endif
 // Chunk Q of the step.  The barrier vouches for chunks Q and Q + 1 (so that the fragment reads can run into the next
 // chunk), then chunk Q + PD starts into the slot chunk Q - 1 was read from.  Group g of the chunk is k-step g of its two
 // output tiles; the reads of group g + 2 (of this chunk or the next) go out before group g's MFMAs.

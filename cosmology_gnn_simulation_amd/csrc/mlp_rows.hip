@@ -255,8 +255,14 @@ int cgnn_mlp_rows(const cgnn_mlp* mlp, const float* x, int64_t n, int32_t ld_x, 
     CGNN_TRY(CGNN_F16X2, D, H, 1)
     CGNN_FOR_EACH_PAIR(CGNN_PAIR)
 #undef CGNN_PAIR
+    // node encoders with 33 .. 64 input features (reference config.py:18 --window_size > 8: data_utils.py:138-145 builds
+    // 3 (W - 1) + W of them, 37 at W = 10), square models from 64 wide
+#define CGNN_WIDE_ENC(T) \
+    CGNN_TRY(CGNN_F32, 2, T, T) CGNN_TRY(CGNN_BF16, 2, T, T) CGNN_TRY(CGNN_F32X3, 2, T, T) CGNN_TRY(CGNN_F16X2, 2, T, T)
+    CGNN_WIDE_ENC(2) CGNN_WIDE_ENC(4) CGNN_WIDE_ENC(8)
+#undef CGNN_WIDE_ENC
 #undef CGNN_TRY
-    set_error("cgnn_mlp_rows: no kernel for in=%d hidden=%d out=%d (supported: input<=32 or output<=32 with "
+    set_error("cgnn_mlp_rows: no kernel for in=%d hidden=%d out=%d (supported: input<=32 (<=64 where hidden == out >= 64) or output<=32 with "
               "(hidden,latent) in {(32,32),(64,64),(128,128),(256,256),(128,64),(128,256)})",
               m.in_dim[0], hidden, m.out_dim[m.nh]);
     return CGNN_ERR_UNSUPPORTED;

@@ -119,12 +119,8 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
     for (; step < a.steps; step += nb) {
         const int64_t row = (step * WAVES + wave) * 16 + c;
         const int64_t next_step = step + nb < a.steps ? step + nb : step;     // last step: re-read its own rows
-#ifdef CGNN_F2R_ABL_XLOAD
-        const int64_t next_row = (blockIdx.x * WAVES + wave) * 16 + c + 0 * next_step;
-#else
         const int64_t next_row0 = (next_step * WAVES + wave) * 16 + c;
         const int64_t next_row = next_row0 < a.n ? next_row0 : a.n - 1;      // rows past the end: the last row again
-#endif
         // the last step may hold fewer than 128 rows: loads are clamped, stores predicated, and its closing wait
         // drains everything (a wave without live rows issues no stores for the counted wait to lean on)
         const bool partial = step == a.steps - 1 && (a.n & 127) != 0;
@@ -194,9 +190,7 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
         const int64_t tile_row = (step * WAVES + wave) * 16;
         const bool ok0 = tile_row + (lane >> 3) < a.n, ok1 = tile_row + (lane >> 3) + 8 < a.n;    // rows of the staged stores
         fold16f2<OT>(c0, c1);
-#ifndef CGNN_F2R_ABL_LN
         layer_norm16<OT>(c0, vec + (NH + 1) * D, vec + (NH + 2) * D, q);
-#endif
         F2R_STAMP(10);
         {
             float* const xo = a.x_out + (tile_row + (lane >> 3)) * D + (lane & 7) * 4;
@@ -211,27 +205,13 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
                 w[4] = c0[2 * p + 1];
                 const LdsF4Ptr r = (LdsF4Ptr)(stage + lane * 16);
                 const f32x4 v0 = r[0], v1 = r[64];
-#ifdef CGNN_F2R_ABL_XSTORE
-                asm volatile("" ::"v"(v0), "v"(v1), "v"(xo));
-#else
                 if (ok0) *reinterpret_cast<f32x4*>(xo + p * 32) = v0;
                 if (ok1) *reinterpret_cast<f32x4*>(xo + p * 32 + 8 * D) = v1;
-#endif
             }
         }
         F2R_STAMP(11);
-#ifdef CGNN_F2R_ABL_PMFMA
-#define F2R_PMFMA(ACC, OPB, W) asm volatile("" ::"v"(OPB[0]), "v"(OPB[KS - 1]))
-#else
 #define F2R_PMFMA(ACC, OPB, W) dense16_pipelined<KS, OT, 3>(ACC, OPB, W, lane)
-#endif
-#ifdef CGNN_F2R_ABL_PSTORE
-#define F2R_PSTORE(ACC, BASE)                                                                                     \
-    asm volatile("" ::"v"(ACC[0]), "v"(ACC[1]), "v"(ACC[2]), "v"(ACC[3]), "v"(ACC[4]), "v"(ACC[5]), "v"(ACC[6]), \
-                 "v"(ACC[7]))
-#else
 #define F2R_PSTORE(ACC, BASE) store_p(ACC, BASE)
-#endif
         // CGNN_P_BF16_S32 rows (feature 32t + 8g + 4h + i at h * 64 + (4t + g) * 4 + i): tile O of lane (c, q) is 8 bytes at
         // h = q & 1, 4t + g = 4 (O >> 1) + 2 (O & 1) + (q >> 1); four tiles fill 64 bytes of each half of the row
         auto store_p = [&](const f32x4 (&acc)[OT], __bf16* base) {
@@ -284,14 +264,10 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
         F2R_STAMP(12);
         // younger than the row loads: 8 x_out stores and the P-row stores (4 per table); the count names fewer than were
         // issued, the safe side
-#if defined(CGNN_F2R_ABL_PSTORE) || defined(CGNN_F2R_ABL_XSTORE)
-        rows_ready<0>(xn, an);
-#else
         if (partial)
             rows_ready<0>(xn, an);
         else
             rows_ready<8>(xn, an);
-#endif
         F2R_STAMP(13);
     }
     // the last steps' wrapped chunks are still on their way into this workgroup's LDS

@@ -102,13 +102,6 @@ __device__ __forceinline__ bf16x8 p32_selector(int lane, int s) {
 template <int DT, class Fill>
 __device__ __forceinline__ void selp32(f32x16 (&acc)[DT], const bf16x8 (&ps)[2 * DT], const bf16x8 (&pd)[2 * DT], bf16x8 sel0,
                                        bf16x8 sel1, const Fill& fill) {
-#ifdef CGNN_S32_ABLATE_SELP
-#pragma unroll
-    for (int t = 0; t < DT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    return;
-#endif
     static_for_each([&](auto tc) __attribute__((always_inline)) {
         constexpr int t = decltype(tc)::value;
         f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};

@@ -133,8 +133,9 @@ class TrainPacks:
             if m.hidden != self.hidden or not pair_ok:
                 raise CgnnError(f"training kernels are built for mlp_hidden_size == latent_size in (32, 64, 128, 256) and for "
                                 f"mlp_hidden_size 128 with latent_size 64 or 256; got hidden {m.hidden}, latent {D}")
-        if self.enc.in1 > 32:
-            raise CgnnError(f"training kernels take at most 32 node input features (got {self.enc.in1})")
+        if self.enc.in1 > 64 or (self.enc.in1 > 32 and (self.hidden != D or D < 64)):
+            raise CgnnError(f"training kernels take at most 64 node input features (window_size <= 16), more than 32 only with "
+                            f"mlp_hidden_size == latent_size >= 64 (got {self.enc.in1} features, hidden {self.hidden}, latent {D})")
         self.nh = self.enc.nh
         self.edge_stream_fn = None      # set per call by EncodeProcessDecode._forward_train when model.train_edge_stream
 

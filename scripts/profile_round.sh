@@ -12,8 +12,9 @@ cd /tmp && export TMPDIR=/tmp
 echo "== bench under rocprofv3 --kernel-trace --stats"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err || echo "bench profile failed"
 cp $OUT/bench/*/*kernel_stats.csv $OUT/bench_kernel_stats.csv 2>/dev/null
-pmc() {   # name op args... -- then counter sets
+pmc() {   # name op args... -- then counter sets      (ONLY="edge_stream node_block": just those passes)
   local name=$1 op=$2; shift 2
+  if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $name "; then return; fi
   local args=()
   while [ "$1" != "--" ]; do args+=("$1"); shift; done; shift
   local i=0

@@ -64,15 +64,21 @@ if a.op == "edge_stream":
     if imageL is not None:
         imageL, kernL = mL._edge_stream_plan(PL, fk, n * k, ea)
     encL = None if imageL is not None else (PL["enc_edge"] if mL._encoder_fits_stream(PL) else None)
-    ps_all = torch.randn(L, n, d, device=dev, generator=gen).to(torch.bfloat16)
-    pd_all = torch.randn(L, n, d, device=dev, generator=gen).to(torch.bfloat16)
+    # the table format the model itself would hand this kernel (fp16 rows for the two-waves-per-SIMD kernel)
+    pdtL = ops.p_format_dtype(graph_network.stream_table_format(PL["rounds"], kernL if imageL is not None else None, mL.edge_stream_lag))
+    ps_all = torch.randn(L, n, d, device=dev, generator=gen).to(pdtL)
+    pd_all = torch.randn(L, n, d, device=dev, generator=gen).to(pdtL)
 if a.op == "node_block_proj":     # the node block as the fused forward runs it: next round's projections inside
     m2 = graph_network.EncodeProcessDecode(d, d, 2, 2, 3)
     m2.load_state_dict(synthetic.make_state_dict(d, d, 2, 2, 3))
     m2 = m2.to(dev).eval()
     m2.edge_precision, m2.node_precision = a.edge_precision, a.node_precision
-    r0, r1 = m2._pack(17, 4)["rounds"]
-    ps2, pd2 = ops.project_nodes(r1.ws, r1.wd, x, None, None, r1.p_format)
+    P2 = m2._pack(17, 4)
+    r0, r1 = P2["rounds"]
+    # ... in the table format of the forward's edge stream (graph_network.stream_table_format)
+    kern2 = m2._edge_stream_plan(P2, fk, n * k, ea)[1] if P2["image"] is not None else None
+    fmt2 = graph_network.stream_table_format(P2["rounds"], kern2, int(getattr(m2, "edge_stream_lag", 0)))
+    ps2, pd2 = ops.project_nodes(r1.ws, r1.wd, x, None, None, fmt2)
 if a.op == "aggregate_planned":
     plan_ = ops.AggregatePlan(src, n, fk)
 if a.op == "scatter_shuffled":      # general edge list (fixed_k = 0), shuffled: one float atomic row per edge
@@ -82,7 +88,7 @@ fn = {
     "aggregate_planned": lambda: ops.aggregate(x, src, dst, n, fk, n * k, agg, plan=plan_),
     "scatter_shuffled": lambda: ops.aggregate(x, src_sh, dst_sh, n, 0, n * k, agg),
     "node_block_proj": lambda: ops.node_block(r0.node, r0.wx, r0.wa, x, agg, x, True,
-                                              (r1.ws_fused, r1.wd_fused, ps2, pd2, r1.p_format)),
+                                              (r1.ws_fused, r1.wd_fused, ps2, pd2, fmt2)),
     "edge_stream": lambda: (ops.edge_stream_run(imageL, ps_all, pd_all, src, dst, None if imageL.enc_in else e, e,
                                                 ea if imageL.enc_in else None, kernel=kernL, lag=mL.edge_stream_lag,
                                                 fixed_k=fk) if imageL is not None else

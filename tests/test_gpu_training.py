@@ -290,6 +290,53 @@ def test_training_step_gradients_match_reference_autograd(n, k, latent, nh, step
             assert _close(got[name].grad, ref.grad, gtol if ref.grad.numel() > 1 else 5 * gtol), name
 
 
+@pytest.mark.parametrize("window,latent", [(10, 128), (16, 64)])
+@pytest.mark.parametrize("train_precision", ["fp32", "fp32x3"])
+def test_training_step_with_a_window_longer_than_eight_frames(window, latent, train_precision):
+    """--window_size > 8 (reference config.py:18; data_utils.py:138-145 builds 3 (W - 1) + W node features: 37 at W = 10, 61 at
+    W = 16): the encoder's backward takes up to 64 input features (two 32-feature tiles, the second one ragged).  Same
+    gates as the W = 5 models."""
+    n, k, nh, steps = 800, 8, 2, 2
+    g, sd, dt = _problem(n, k, latent, nh, steps, seed=300 + window, window=window)
+    assert g.x.shape[1] == 3 * (window - 1) + window
+    want_loss, sdr, want_dx, want_out = _reference_grads(sd, g, nh, steps, dt)
+    model = graph_network.EncodeProcessDecode(latent, latent, nh, steps, 3)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    model.train_precision = train_precision
+    g.x.requires_grad_(True)
+    pred = model(g)
+    mse = torch.nn.functional.mse_loss
+    loss = (mse(pred["acceleration"], g.y_acc) + 0.5 * mse(pred["temp_rate"], g.y_temp_rate)
+            + losses.momentum_conservation_loss(pred["acceleration"], g, dt, 0.1))
+    loss.backward()
+    assert _close(pred["acceleration"], want_out["acceleration"], 1e-5)
+    assert _close(pred["temp_rate"], want_out["temp_rate"], 1e-5)
+    assert _close(g.x.grad, want_dx, GTOL)
+    got = dict(model.named_parameters())
+    for name, ref in sdr.items():
+        if ".edge_model." in name:
+            assert ref.grad is None and got[name].grad is None, name
+        else:
+            assert got[name].grad is not None, name
+            assert _close(got[name].grad, ref.grad, GTOL if ref.grad.numel() > 1 else 5 * GTOL), name
+    # the same window through the inference kernels (every node precision the bench presets use)
+    model.eval()
+    for node_precision in ("fp32", "fp16x2"):
+        model.node_precision = node_precision
+        with torch.no_grad():
+            out = model(g)
+        assert _close(out["acceleration"], want_out["acceleration"], 1e-5), node_precision
+        assert _close(out["temp_rate"], want_out["temp_rate"], 1e-5), node_precision
+    # 65 features and more: refused (the backward is compiled for two input tiles)
+    g17, sd17, _ = _problem(300, 8, 64, 2, 1, seed=9, window=17)
+    m17 = graph_network.EncodeProcessDecode(64, 64, 2, 1, 3)
+    m17.load_state_dict(sd17)
+    m17 = m17.to(DEV).train()
+    with pytest.raises(ops.CgnnError, match="64 node input features"):
+        m17(g17)
+
+
 @pytest.mark.parametrize("n,k,latent,hidden,nh,steps", [(700, 8, 64, 128, 2, 3), (400, 16, 256, 128, 2, 2)])
 @pytest.mark.parametrize("train_precision", ["fp32", "fp32x3"])
 def test_training_step_with_hidden_size_other_than_latent(n, k, latent, hidden, nh, steps, train_precision):
