@@ -23,6 +23,7 @@ ap.add_argument("--mp-steps", type=int, default=10)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--variants", default="tile32,tile32w:0,tile32w:1")
 ap.add_argument("--no-encoder", action="store_true")
+ap.add_argument("--bf16-tables", action="store_true", help="tile32w: bf16 P tables (selector MFMAs) instead of the model's fp16 ones")
 ap.add_argument("--fixed-k", type=int, default=1, help="0: do not tell the kernel about the graph's fixed in-degree")
 a = ap.parse_args()
 dev = "cuda"
@@ -42,6 +43,8 @@ images = {k: ops.StreamImage(*parts, kernel=k) for k in ("tile32", "tile32w")}
 E = n * k
 ps_all = torch.randn(L, n, d, device=dev).to(torch.bfloat16)
 pd_all = torch.randn(L, n, d, device=dev).to(torch.bfloat16)
+# what the model feeds the two-waves-per-SIMD kernel (lag 0): the same tables in fp16 (CGNN_P_F16_S32)
+ps16, pd16 = ps_all.to(torch.float16), pd_all.to(torch.float16)
 ea = torch.randn(E, 4, device=dev)
 e = ops.TiledRows.from_rows(torch.randn(E, d, device=dev))
 flops = L * 6.0 * E * d * d + (0 if a.no_encoder else 2.0 * E * (32 * d + 2 * d * d))
@@ -52,10 +55,11 @@ for v in a.variants.split(","):
 
 
 def run(kern, lag):
+    ps_, pd_ = (ps16, pd16) if (kern == "tile32w" and (lag == 2 or (lag == 0 and not a.bf16_tables))) else (ps_all, pd_all)
     if a.no_encoder:
-        ops.edge_stream_run(images[kern], ps_all, pd_all, src, dst, e, e, None, kernel=kern, lag=lag, fixed_k=fk if a.fixed_k else 0)
+        ops.edge_stream_run(images[kern], ps_, pd_, src, dst, e, e, None, kernel=kern, lag=lag, fixed_k=fk if a.fixed_k else 0)
     else:
-        ops.edge_stream_run(images[kern], ps_all, pd_all, src, dst, None, e, ea, kernel=kern, lag=lag, fixed_k=fk if a.fixed_k else 0)
+        ops.edge_stream_run(images[kern], ps_, pd_, src, dst, None, e, ea, kernel=kern, lag=lag, fixed_k=fk if a.fixed_k else 0)
 
 
 times = {v[0]: [] for v in variants}
