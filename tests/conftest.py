@@ -72,8 +72,11 @@ def edge_index_from(g):
 
 
 def rel_err(a, b):
+    """The larger of the two norms SURVEY 8(d) names for the f32 gates: max-abs / max-abs and relative L2."""
     a, b = a.double(), b.double()
-    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    linf = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    l2 = float((a - b).norm() / b.norm().clamp_min(1e-30))
+    return max(linf, l2)
 
 
 def rel_l2(a, b):

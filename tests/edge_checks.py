@@ -18,16 +18,10 @@ are per ROW, evaluated on the device in chunks (the matrices are 8-33 GB at the 
 import contextlib
 
 import torch
-import torch.nn.functional as F
 
-
-def bf(t):
-    return t.bfloat16().float()
-
-
-def dot_bf16(a, w):
-    """bf16 operands, wide accumulation (the MFMA's f32 accumulation order is not reproduced; f64 is the midpoint)."""
-    return (bf(a).double() @ bf(w).double().t()).float()
+# the bf16-operand arithmetic itself is part of the oracle (oracle/bf16_stream.py: reference citations, pinned against
+# cpu_ref on the CPU in every run); this file keeps the gates
+from oracle.bf16_stream import bf, dot_bf16, emulate_edge_stream_rows, s32_table_to_logical  # noqa: F401
 
 
 def row_rel_max(a: torch.Tensor, b: torch.Tensor, chunk: int = 1 << 20):
@@ -69,52 +63,6 @@ def sample_rows(num_edges: int, n_random: int = 4096, seed: int = 0, device="cud
     picks.append(torch.randint(0, num_edges, (n_random,), generator=gen, dtype=torch.int64))
     rows = torch.unique(torch.cat(picks))
     return rows[rows < num_edges].to(device)
-
-
-def s32_table_to_logical(table: torch.Tensor) -> torch.Tensor:
-    """CGNN_P_BF16_S32 (include/cgnn.h): feature f = 32t + 8g + 4h + c is stored at h*(H/2) + (4t + g)*4 + c.
-    -> float32 values in feature order (last dimension)."""
-    H = table.shape[-1]
-    f = torch.arange(H, device=table.device)
-    t, g, h, c = f // 32, (f % 32) // 8, (f % 8) // 4, f % 4
-    pos = h * (H // 2) + (4 * t + g) * 4 + c
-    return table[..., pos].float()
-
-
-def _mlp_tail(h0, lins, ln):
-    """h0 = pre-activation of layer 0 (bias included); lins = [(w, b)] of layers 1..; ln = (gamma, beta)."""
-    h = bf(torch.relu(h0))
-    for w, b in lins[:-1]:
-        h = bf(torch.relu(dot_bf16(h, w) + b))
-    w, b = lins[-1]
-    out = dot_bf16(h, w) + b
-    return F.layer_norm(out, (out.shape[1],), ln[0], ln[1], 1e-5)
-
-
-def emulate_edge_stream_rows(sd: dict, rows: torch.Tensor, stream_inputs: dict, latent: int, nh: int, rounds: int,
-                             with_encoder: bool = True) -> torch.Tensor:
-    """The edge latents after ``rounds`` residual updates for the edge rows ``rows`` (engine numbering), from the
-    reference's parameters ``sd`` (state_dict keys of graph_network.py:133-148) and the tables the kernel read."""
-    dev = rows.device
-    D = latent
-    W = lambda k: sd[k].to(dev)      # noqa: E731
-    src, dst = stream_inputs["src"][rows].long(), stream_inputs["dst"][rows].long()
-    if with_encoder:
-        pre = "encoder.edge_model"
-        lins = [(W(f"{pre}.0.{2 * i}.weight"), W(f"{pre}.0.{2 * i}.bias")) for i in range(nh + 1)]
-        attr = stream_inputs["edge_attr"][rows]
-        e = _mlp_tail(dot_bf16(attr, lins[0][0]) + lins[0][1], lins[1:], (W(f"{pre}.1.weight"), W(f"{pre}.1.bias")))
-    else:
-        e = stream_inputs["e_in"][rows].clone()
-    for r in range(rounds):
-        pre = f"processor.{r}.edge_model"
-        w0 = W(f"{pre}.0.0.weight")
-        lins = [(W(f"{pre}.0.{2 * i}.weight"), W(f"{pre}.0.{2 * i}.bias")) for i in range(1, nh + 1)]
-        ps = s32_table_to_logical(stream_inputs["ps_all"][r][src])
-        pd = s32_table_to_logical(stream_inputs["pd_all"][r][dst])       # carries the layer-0 bias
-        first = (ps + pd) + dot_bf16(e, w0[:, 2 * D:3 * D])
-        e = e + _mlp_tail(first, lins, (W(f"{pre}.1.weight"), W(f"{pre}.1.bias")))
-    return e
 
 
 def assert_rows_match_emulation(got_rows: torch.Tensor, want_rows: torch.Tensor, rows: torch.Tensor, what="edge latents"):
