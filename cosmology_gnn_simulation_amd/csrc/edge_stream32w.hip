@@ -48,7 +48,9 @@ struct W8Geom {
     static constexpr unsigned LNBUF_OFF = CGNN_W8_SLOTS * STRIDE;                  // two (gamma | beta) buffers behind the ring
     static constexpr unsigned LNBUF_BYTES = 2u * D * 4u;
     static constexpr unsigned PDST_OFF = LNBUF_OFF + 2u * LNBUF_BYTES;           // per wave: the tile's receiver P rows (<= 4 rows)
-    static constexpr unsigned PDST_BYTES = 64u * 16u;
+    static constexpr unsigned PDST_ROW = 256u + 16u;                             // a receiver's row, padded by one 16-byte bank group:
+                                                                                 // the (<= 4) rows a read touches start in different ones
+    static constexpr unsigned PDST_BYTES = 4u * PDST_ROW;
     static constexpr unsigned PSST_OFF = PDST_OFF + CGNN_W8_WAVES * PDST_BYTES;  // per wave: half of every sender half-row of the tile
     static constexpr unsigned PSST_BYTES = 64u * (unsigned)D / 2u;               // 64 lines x D / 2 bytes (latent 128: 4 KiB)
     static constexpr unsigned LDS = PSST_OFF + CGNN_W8_WAVES * PSST_BYTES;
@@ -449,19 +451,22 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
 #endif
     };
     auto park_pd = [&](u32x4 chunk) __attribute__((always_inline)) {
-        *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(pdst + (unsigned)lane * 16u) = chunk;
+        *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(pdst + (unsigned)(lane >> 4) * W::PDST_ROW + (unsigned)(lane & 15) * 16u) = chunk;
     };
-    const unsigned pd_read = pdst + ((unsigned)(r / kk) * 16u + 8u * (unsigned)h) * 16u;
+    // piece i (0 .. 7) of this lane's half of its receiver's row.  bf16 tables: the half is contiguous (chunk 8 h + i); fp16
+    // tables (CGNN_P_F16_S32) interleave the halves line by line: chunk 8 (i >> 2) + 4 h + (i & 3)
+    const unsigned pd_read = pdst + (unsigned)(r / kk) * W::PDST_ROW + (PF16 ? 4u : 8u) * (unsigned)h * 16u;
+    auto pd_piece = [](int i) constexpr -> unsigned { return PF16 ? (unsigned)(((i >> 2) * 8 + (i & 3)) * 16) : (unsigned)(16 * i); };
     auto read_pd = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2 * DT; ++i)
-            pd[i] = __builtin_bit_cast(bf16x8, *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)(pd_read + 16u * (unsigned)i));
+            pd[i] = __builtin_bit_cast(bf16x8, *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)(pd_read + pd_piece(i)));
     };
     auto read_pd_row = [&](auto tc) __attribute__((always_inline)) {      // the two pieces of row tile t
         constexpr int t = decltype(tc)::value;
 #pragma unroll
         for (int i = 2 * t; i < 2 * t + 2; ++i)
-            pd[i] = __builtin_bit_cast(bf16x8, *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)(pd_read + 16u * (unsigned)i));
+            pd[i] = __builtin_bit_cast(bf16x8, *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)(pd_read + pd_piece(i)));
     };
     u32x4 pdchunk = {0u, 0u, 0u, 0u};
 
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
         // (the constant part of the source offset travels as the scalar offset: the instruction's immediate offset is
         // added to the LDS address as well)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LdsVoidPtrG)dstp, 16, ((i & 1) ? so_hi : so_lo) + ps_cq,
-                                                 (i >> 1) * D + SUB * 64, 0, 0);
+                                                 PF16 ? (i >> 1) * 64 + SUB * 128 : (i >> 1) * D + SUB * 64, 0, 0);
 #endif
         asm volatile("" ::: "memory");
     };

@@ -173,18 +173,18 @@ struct PFmt<CGNN_P_BF16_S32> {
     }
 };
 template <>
-struct PFmt<CGNN_P_F16_S32> {      // CGNN_P_BF16_S32's order, fp16 values
+struct PFmt<CGNN_P_F16_S32> {      // fp16; the two halves of CGNN_P_BF16_S32's row interleaved in 64-byte segments (cgnn.h)
     typedef _Float16 elem;
     template <int HT>
     static __device__ __forceinline__ void store(const f32x16 (&a)[HT], _Float16* b, int64_t row, int h) {
         typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
-        f16x8v* p = reinterpret_cast<f16x8v*>(b + row * (32 * HT) + h * (16 * HT));
+        f16x8v* p = reinterpret_cast<f16x8v*>(b + row * (32 * HT));      // 16-byte pieces of the row
 #pragma unroll
-        for (int j = 0; j < 2 * HT; ++j) {
+        for (int j = 0; j < 2 * HT; ++j) {      // piece j of this lane's half: segment j >> 2, piece j & 3 within it
             f16x8v v;
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[c] = (_Float16)a[j >> 1][8 * (j & 1) + c];
-            p[j] = v;
+            p[(j >> 2) * 8 + h * 4 + (j & 3)] = v;
         }
     }
 };

@@ -591,15 +591,16 @@ __device__ __forceinline__ void layer_norm16_global(f32x4 (&a)[OT], const float*
 template <int PFMT, int OT>
 __device__ __forceinline__ void store_p16(const f32x4 (&acc)[OT], __bf16* __restrict__ base, int64_t row, int q) {
     __bf16* rp = base + row * (16 * OT);
-    if constexpr (PFMT == CGNN_P_F16_S32) {      // CGNN_P_BF16_S32's order, fp16 values (same element size)
+    if constexpr (PFMT == CGNN_P_F16_S32) {      // fp16, the halves interleaved in 64-byte segments (cgnn.h)
         typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int o = 0; o < OT; ++o) {
             const int t = o >> 1, g = 2 * (o & 1) + (q >> 1), hh = q & 1;
+            const int u = (4 * t + g) * 4;      // position within the half
             f16x4v v;
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = (_Float16)acc[o][c];
-            *reinterpret_cast<f16x4v*>(rp + hh * (8 * OT) + (4 * t + g) * 4) = v;
+            *reinterpret_cast<f16x4v*>(rp + (u >> 5) * 64 + hh * 32 + (u & 31)) = v;
         }
     } else if (PFMT == CGNN_P_BF16_S16) {
         bf16x8* p = reinterpret_cast<bf16x8*>(rp) + q;

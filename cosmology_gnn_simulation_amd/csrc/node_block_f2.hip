@@ -216,8 +216,10 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
         // h = q & 1, 4t + g = 4 (O >> 1) + 2 (O & 1) + (q >> 1); four tiles fill 64 bytes of each half of the row
         auto store_p = [&](const f32x4 (&acc)[OT], __bf16* base) {
             if constexpr (PFMT == CGNN_P_BF16_S32 || PFMT == CGNN_P_F16_S32) {
-                char* const pt = reinterpret_cast<char*>(base + (tile_row + (lane >> 3)) * D) + ((lane & 7) >> 2) * 128 +
-                                 (lane & 3) * 16;
+                // bf16: 64 bytes into each half of the row; fp16 (CGNN_P_F16_S32): the staged 128 bytes of a row ARE one line of it
+                char* const pt = reinterpret_cast<char*>(base + (tile_row + (lane >> 3)) * D) +
+                                 (PFMT == CGNN_P_F16_S32 ? (lane & 7) * 16 : ((lane & 7) >> 2) * 128 + (lane & 3) * 16);
+                constexpr int PP_STRIDE = PFMT == CGNN_P_F16_S32 ? 128 : 64;
 #pragma unroll
                 for (int pp = 0; pp < OT / 4; ++pp) {
 #pragma unroll
@@ -238,8 +240,8 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
                     }
                     const LdsU4Ptr r = (LdsU4Ptr)(stage + lane * 16);
                     const u32x4 v0 = r[0], v1 = r[64];
-                    if (ok0) *reinterpret_cast<u32x4*>(pt + pp * 64) = v0;
-                    if (ok1) *reinterpret_cast<u32x4*>(pt + pp * 64 + 8 * D * 2) = v1;
+                    if (ok0) *reinterpret_cast<u32x4*>(pt + pp * PP_STRIDE) = v0;
+                    if (ok1) *reinterpret_cast<u32x4*>(pt + pp * PP_STRIDE + 8 * D * 2) = v1;
                 }
             } else {
                 if (row < a.n) store_p16<PFMT, OT>(acc, base, row, q);

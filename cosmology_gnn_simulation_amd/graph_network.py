@@ -322,7 +322,7 @@ def _run_round(p: _PackedProcessor, x: torch.Tensor, e: torch.Tensor, src, dst, 
 def stream_table_format(rounds, stream_kernel: Optional[str], stream_lag: int = 0) -> int:
     """``cgnn_ptable`` format of the Ps / Pd tables the node stream leaves for the one-launch edge stream.
     ``cgnn_edge_stream_run_w8`` (``"tile32w"``, lag 0) adds ``Ps[src] + Pd[dst]`` on the vector pipe when the tables are fp16
-    (``CGNN_P_F16_S32``: the same order and projection arithmetic, the f32 sums rounded to 11 significand bits instead of
+    (``CGNN_P_F16_S32``: the row's halves interleaved in 64-byte segments, the same projection arithmetic, the f32 sums rounded to 11 significand bits instead of
     bf16's 8): 16 fewer MFMAs per tile and round than the selector MFMAs that bf16 rows need."""
     fmt = rounds[0].p_format
     if stream_kernel == "tile32w" and stream_lag == 0 and fmt == _lib.P_BF16_S32:

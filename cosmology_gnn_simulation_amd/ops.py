@@ -395,7 +395,7 @@ def edge_stream_run(image: StreamImage, ps_all: torch.Tensor, pd_all: torch.Tens
                     fixed_k: int = 0) -> TiledRows:
     """All residual edge updates of ``image`` in one launch.  ``ps_all`` / ``pd_all``: ``[rounds, N, latent]`` bf16
     tables in ``CGNN_P_BF16_S32`` format -- or, ``"tile32w"`` with ``lag = 0`` only, float16 tables in ``CGNN_P_F16_S32``
-    format (the same order; the kernel then adds ``Ps[src] + Pd[dst]`` on the vector pipe instead of through selector
+    format (include/cgnn.h; the kernel then adds ``Ps[src] + Pd[dst]`` on the vector pipe instead of through selector
     MFMAs: what the model runs).  When the image starts with the encoder the initial latents come from
     ``edge_attr`` and ``e_in`` is ignored.  ``kernel``: ``"tile32"`` = ``cgnn_edge_stream_run`` (one wave per SIMD, two
     tiles per wave), ``"tile32w"`` = ``cgnn_edge_stream_run_w8`` (two waves per SIMD, one tile each; ``lag`` and

@@ -76,8 +76,11 @@ typedef enum {
  *   CGNN_P_BF16_S32  bf16, f = 32t+8g+4h+c at h*(H/2) + (4t+g)*4 + c      (mlp precision CGNN_BF16)
  *   CGNN_P_BF16_S16  bf16, f = 16O+4q+i    at (4*(O/2) + q)*8 + 4*(O%2) + i   (mlp precision CGNN_BF16_N16: the
  *                    16-edge kernel's MFMA B-operand order, so the rows enter the accumulators through the matrix pipe)
- *   CGNN_P_F16_S32   IEEE fp16 in CGNN_P_BF16_S32's order (projection weights CGNN_BF16 / CGNN_BF16_N16, the f32 sums
- *                    rounded to fp16: 11 significand bits instead of 8, |value| < 65520): the table format of
+ *   CGNN_P_F16_S32   IEEE fp16 (projection weights CGNN_BF16 / CGNN_BF16_N16, the f32 sums rounded to fp16: 11
+ *                    significand bits instead of 8, |value| < 65520), H = 128 only; with u = (4t+g)*4 + c the position of
+ *                    f within CGNN_P_BF16_S32's half h, f sits at (u/32)*64 + h*32 + u%32: the halves are interleaved in
+ *                    64-byte segments, so that a 128-byte line holds what a 16-row writer produces per row at a time
+ *                    (whole-line stores) and both halves of a gathered sub-row share one line.  The table format of
  *                    cgnn_edge_stream_run_w8, which adds Ps[src] + Pd[dst] on the vector pipe with one v_fma_mix_f32 per
  *                    value (fp16 widens for free there; bf16 rows need four selector MFMAs per row tile instead)
  * i.e. each lane of the consuming kernel reads one contiguous run. */

@@ -42,14 +42,21 @@ def round_to(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return t.to(dtype).float()
 
 
-def s32_table_to_logical(table: torch.Tensor) -> torch.Tensor:
-    """CGNN_P_BF16_S32 (include/cgnn.h): feature f = 32t + 8g + 4h + c is stored at h*(H/2) + (4t + g)*4 + c.
-    -> float32 values in feature order (last dimension)."""
-    H = table.shape[-1]
-    f = torch.arange(H, device=table.device)
+def s32_position(H: int, dtype: torch.dtype, device=None) -> torch.Tensor:
+    """Where feature f = 32t + 8g + 4h + c of a row sits in the engine's gather tables (include/cgnn.h, cgnn_ptable):
+    CGNN_P_BF16_S32 (bfloat16): h*(H/2) + u with u = (4t + g)*4 + c; CGNN_P_F16_S32 (float16, H = 128): the two halves
+    interleaved in 64-byte segments, (u/32)*64 + h*32 + u%32."""
+    f = torch.arange(H, device=device)
     t, g, h, c = f // 32, (f % 32) // 8, (f % 8) // 4, f % 4
-    pos = h * (H // 2) + (4 * t + g) * 4 + c
-    return table[..., pos].float()
+    u = (4 * t + g) * 4 + c
+    if dtype == torch.float16:
+        return (u // 32) * 64 + h * 32 + u % 32
+    return h * (H // 2) + u
+
+
+def s32_table_to_logical(table: torch.Tensor) -> torch.Tensor:
+    """A CGNN_P_BF16_S32 (bfloat16) or CGNN_P_F16_S32 (float16) table -> float32 values in feature order (last dimension)."""
+    return table[..., s32_position(table.shape[-1], table.dtype, table.device)].float()
 
 
 def _mlp_tail(h0, lins, ln):

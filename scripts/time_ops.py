@@ -116,8 +116,12 @@ if not a.only or a.only == "aggregate_atomic":
 t("node_block", lambda: ops.node_block(p.node, p.wx, p.wa, x, agg, x, True), 3 * n * d * 4, 8.0 * n * d * d)
 if len(roundsL) > 1 and roundsL[0].node.precision in _lib.N16_NODE:      # 16-row node kernels: projections of the next round fused in
     q_ = roundsL[1]
+    # ... in the table format the forward's edge stream takes (fp16 rows for the two-waves-per-SIMD kernel)
+    kern_ = mL._edge_stream_plan(PL_, fk, E, ea)[1] if PL_["image"] is not None else None
+    fmt_ = graph_network.stream_table_format(roundsL, kern_, int(getattr(mL, "edge_stream_lag", 0)))
+    psf_, pdf_ = ps.to(ops.p_format_dtype(fmt_)), pd.to(ops.p_format_dtype(fmt_))
     t("node_block+proj", lambda: ops.node_block(roundsL[0].node, roundsL[0].wx, roundsL[0].wa, x, agg, x, True,
-                                                (q_.ws_fused, q_.wd_fused, ps, pd, q_.p_format)),
+                                                (q_.ws_fused, q_.wd_fused, psf_, pdf_, fmt_)),
       3 * n * d * 4 + 2 * n * d * 2, 8.0 * n * d * d)
 t("project_nodes", lambda: ops.project_nodes(p.ws, p.wd, x, ps, pd, p.p_format), 3 * n * d * 4, 4.0 * n * d * d)
 t("enc_edge", lambda: ops.mlp_rows(P["enc_edge"], ea, out=e), E * (16 + d * 4), 2.0 * E * (32 * d + 2 * d * d))

@@ -24,11 +24,9 @@ def _dot(a, w):      # bf16 operands, wide accumulation
 
 def _s32_table(p, dtype=torch.bfloat16):
     """logical [R, N, H] values -> table in CGNN_P_BF16_S32 order (include/cgnn.h): feature f = 32t+8g+4h+c sits at
-    h*(H/2) + (4t+g)*4 + c; ``dtype`` float16 = CGNN_P_F16_S32 (the same order)."""
-    H = p.shape[-1]
-    f = torch.arange(H, device=p.device)
-    t, g, h, c = f // 32, (f % 32) // 8, (f % 8) // 4, f % 4
-    pos = h * (H // 2) + (4 * t + g) * 4 + c
+    h*(H/2) + (4t+g)*4 + c; ``dtype`` float16 = CGNN_P_F16_S32 (halves interleaved in 64-byte segments)."""
+    from oracle.bf16_stream import s32_position
+    pos = s32_position(p.shape[-1], dtype, p.device)
     out = torch.empty_like(p)
     out[..., pos] = p
     return out.to(dtype).contiguous()

@@ -107,7 +107,7 @@ def test_fp16x2_overflow_is_loud():
 
 
 @pytest.mark.parametrize("fmt", ["fp32x3_n16", "fp16x2_n16"])
-@pytest.mark.parametrize("p_format", [_lib.P_BF16_S32, _lib.P_BF16_S16])
+@pytest.mark.parametrize("p_format", [_lib.P_BF16_S32, _lib.P_BF16_S16, _lib.P_F16_S32])
 def test_node_block_fused_projection_epilogue(fmt, p_format):
     """next round's Ps / Pd written by the node kernel == cgnn_project_nodes on its output (same bf16 MFMA products)."""
     n, d = 3000, 128
@@ -121,7 +121,7 @@ def test_node_block_fused_projection_epilogue(fmt, p_format):
     w1, b1 = lin[0]
     wx, wa = ops.PackedLinear(w1, b1, fmt, 0, d), ops.PackedLinear(w1, None, fmt, d, d)
     mlp = ops.PackedMLP([(w1[:, :d].contiguous(), None)] + lin[1:], ln, fmt)
-    ps = torch.empty(n, d, dtype=torch.bfloat16, device=DEV)
+    ps = torch.empty(n, d, dtype=ops.p_format_dtype(p_format), device=DEV)
     pd = torch.empty_like(ps)
     out = ops.node_block(mlp, wx, wa, x, agg, None, True, (ws16, wd16, ps, pd, p_format))
     plain = ops.node_block(mlp, wx, wa, x, agg, None, True)
@@ -131,8 +131,17 @@ def test_node_block_fused_projection_epilogue(fmt, p_format):
     torch.cuda.synchronize()
     for a, b in ((ps, ps2), (pd, pd2)):
         diff = (a.float() - b.float()).abs()
-        assert float(diff.max()) <= 2.0 ** -7 * float(b.float().abs().max())      # at most a bf16 rounding flip
+        assert float(diff.max()) <= 2.0 ** -7 * float(b.float().abs().max())      # at most a bf16 (fp16) rounding flip
         assert float((diff > 0).float().mean()) < 0.02
+    if p_format == _lib.P_F16_S32:
+        # the fp16 tables hold the SAME projections as the bf16 ones, rounded to 11 bits instead of 8 and laid out with the
+        # row's halves interleaved in 64-byte segments (include/cgnn.h): oracle.bf16_stream.s32_position is that order
+        from oracle.bf16_stream import s32_table_to_logical
+        pb, db = ops.project_nodes(ws, wd, out, None, None, _lib.P_BF16_S32)
+        for f16, b16 in ((ps, pb), (pd, db)):
+            lf, lb = s32_table_to_logical(f16), s32_table_to_logical(b16)
+            assert float((lf - lb).abs().max()) <= 2.0 ** -8 * float(lb.abs().max())      # half a bf16 unit in the last place
+            assert float((lf - lb).abs().mean()) > 0      # (and not the same numbers: fp16 keeps three more bits)
 
 
 @pytest.mark.parametrize("n,d,h,nh", [(1000, 256, 256, 2), (333, 64, 128, 2), (70, 256, 128, 1), (2000, 128, 128, 2),

@@ -62,9 +62,7 @@ def test_row_subset_form_equals_the_all_edges_form():
             ps_all.append(bf16_stream.dot_bf16(xr, w0[:, 0:D]).bfloat16())
             pd_all.append((bf16_stream.dot_bf16(xr, w0[:, D:2 * D]) + b0).bfloat16())
         # logical order -> CGNN_P_BF16_S32 order (the inverse of s32_table_to_logical)
-        f = torch.arange(D)
-        t, gq, h, c = f // 32, (f % 32) // 8, (f % 8) // 4, f % 4
-        pos = h * (D // 2) + (4 * t + gq) * 4 + c
+        pos = bf16_stream.s32_position(D, torch.bfloat16)
         def to_s32(p):
             out = torch.empty_like(p)
             out[..., pos] = p
