@@ -271,3 +271,38 @@ def test_integration_notes_name_every_abi_entry():
     notes = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert len(declared) > 30
     assert [d for d in sorted(declared) if d not in notes] == []
+
+
+def test_bench_presets_follow_baseline_json(monkeypatch):
+    """bench.py's --config presets are BASELINE.json's configs (particles, neighbours, latent, rounds), seeds 1234 + the
+    configuration number; N > 1 defaults to weak scaling WITH the strong-scaling leg of the headline box
+    (BASELINE.json: 'at 1M particles ... 1/2/4/8 GPU'), cfg4 / cfg5 to strong scaling of their own totals."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    try:
+        import bench
+    finally:
+        sys.path.pop(0)
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+
+    def parse(*argv):
+        monkeypatch.setattr(sys, "argv", ["bench.py", *argv])
+        return bench.parse_args()
+
+    a = parse()
+    assert (a.gpus, a.particles, a.neighbors, a.latent, a.mp_steps, a.edge_precision, a.seed) == (1, 1_000_000, 16, 128, 10, "bf16", 1237)
+    want = {"cfg1": (4096, 8, 64, 5), "cfg2": (262144, 16, 128, 10), "cfg3": (1_000_000, 16, 128, 10),
+            "cfg4": (4_000_000, 16, 128, 10), "cfg5": (1_000_000, 32, 256, 15)}
+    mult = {"k": 1024, "M": 1_000_000}      # "4k" = 4,096 and "256k" = 262,144 (SURVEY section 8), "1M" = 1,000,000
+    for i, (name, shape) in enumerate(want.items()):
+        a = parse("--config", name)
+        assert (a.particles, a.neighbors, a.latent, a.mp_steps) == shape, name
+        assert a.seed == 1234 + i + 1, name
+        m = re.match(r"(\d+)([kM]) particles, k=(\d+), latent=(\d+), (\d+) MP steps", base["configs"][i])
+        assert m, base["configs"][i]
+        assert (int(m.group(1)) * mult[m.group(2)], int(m.group(3)), int(m.group(4)), int(m.group(5))) == shape, name
+    assert parse("--gpus", "8").scaling == "weak" and not parse("--gpus", "8").no_strong_leg
+    assert parse("--gpus", "8", "--config", "cfg4").scaling == "strong"
+    assert parse("--gpus", "8", "--config", "cfg5").scaling == "strong"
+    assert parse("--gpus", "8", "--scaling=strong").scaling == "strong"
