@@ -20,6 +20,7 @@ MAX_HIDDEN_LAYERS = 6
 F32, BF16, BF16_N16, F32X3, F32X3_N16, F16X2_N16, F16X2 = 0, 1, 2, 3, 4, 5, 6  # cgnn_precision
 N16_NODE = (F32X3_N16, F16X2_N16)       # node-kernel packings whose epilogue fuses the next round's projections
 P_F32, P_BF16_S32, P_BF16_S16, P_F16_S32 = 0, 1, 2, 3  # cgnn_ptable
+STREAM_FOLDED = 1  # cgnn_edge_stream_run_w8 flags: CGNN_STREAM_FOLDED
 LDS_WEIGHT_BUDGET = 152 * 1024           # CGNN_LDS_WEIGHT_BUDGET in csrc/mlp_device.hpp
 PRECISIONS = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "bf16_n16": BF16_N16,
               "fp32x3": F32X3, "f32x3": F32X3, "fp32x3_n16": F32X3_N16, "fp16x2_n16": F16X2_N16,
@@ -95,7 +96,7 @@ def load() -> C.CDLL:
     lib.cgnn_edge_stream_run.argtypes = [vp, sz, i32, i32, i32, i32, vp, vp, i64, vp, vp, i64, vp, vp, vp, i32, vp]
     lib.cgnn_edge_stream_w8_supported.argtypes = [i32, i32, i32]
     lib.cgnn_edge_stream_image_build_w8.argtypes = [C.POINTER(Mlp), i32, C.POINTER(Mlp), i32, vp, sz, vp]
-    lib.cgnn_edge_stream_run_w8.argtypes = [vp, sz, i32, i32, i32, i32, vp, vp, i64, vp, vp, i64, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.cgnn_edge_stream_run_w8.argtypes = [vp, sz, i32, i32, i32, i32, vp, vp, i64, vp, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.cgnn_aggregate.argtypes = [vp, i32, vp, vp, i64, i32, i64, i32, vp, vp]
     lib.cgnn_aggregate_plan_bytes.restype = sz
     lib.cgnn_aggregate_plan_bytes.argtypes = [i64, i32]

@@ -252,31 +252,36 @@ __device__ __forceinline__ void ln_sums_clear(LnSums& a) {
 }
 // registers [8 S, 8 S + 8) of row tile T join the sums: 16 vector instructions, placed by the caller (behind the MFMAs
 // of the NEXT row tile, whose matrix time covers them and the wait for this row tile's last MFMA)
-template <int DT, int T, int S>
+template <bool ZM, int DT, int T, int S>
 __device__ __forceinline__ void ln_sums_add(LnSums& a, const f32x16 (&acc)[DT]) {
 #pragma unroll
     for (int i = 8 * S; i < 8 * S + 8; i += 4) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            a.s[c] += acc[T][i + c];
+            if constexpr (!ZM) a.s[c] += acc[T][i + c];
             a.q[c] = __builtin_fmaf(acc[T][i + c], acc[T][i + c], a.q[c]);
         }
     }
 }
-template <int DT>
+template <bool ZM, int DT>
 __device__ __forceinline__ LnStats ln_stats_finish(const LnSums& a) {
     constexpr int D = 32 * DT;
-    const float mean = half_swap_sum((a.s[0] + a.s[1]) + (a.s[2] + a.s[3])) * (1.0f / D);
     const float ex2 = half_swap_sum((a.q[0] + a.q[1]) + (a.q[2] + a.q[3])) * (1.0f / D);
     LnStats st;
-    st.rstd = __builtin_amdgcn_rsqf(__builtin_fmaxf(__builtin_fmaf(-mean, mean, ex2), 0.f) + 1e-5f);
-    st.nmr = -mean * st.rstd;
+    if constexpr (ZM) {
+        st.rstd = __builtin_amdgcn_rsqf(ex2 + 1e-5f);
+        st.nmr = 0.f;
+    } else {
+        const float mean = half_swap_sum((a.s[0] + a.s[1]) + (a.s[2] + a.s[3])) * (1.0f / D);
+        st.rstd = __builtin_amdgcn_rsqf(__builtin_fmaxf(__builtin_fmaf(-mean, mean, ex2), 0.f) + 1e-5f);
+        st.nmr = -mean * st.rstd;
+    }
     return st;
 }
 // gamma / beta of a slice (eight features: two 16-byte pieces of each vector) are read one slice ahead (plain LDS loads:
 // hand-issued asm reads with early-clobber register quads cost this kernel 60-110 spilled registers); the scheduling
 // barrier per slice keeps the compiler from hoisting every slice's reads to the top (128 registers at latent 128).
-template <bool RES, int DT, int K0, int K1>
+template <bool RES, bool BETA, bool ZM, int DT, int K0, int K1>
 __device__ __forceinline__ void ln_affine_w(const f32x16 (&acc)[DT], f32x16 (&ev)[DT], bf16x8 (&in)[2 * DT], unsigned lnv, int h,
                                             LnStats st) {
     if constexpr (K1 > K0) {
@@ -286,7 +291,7 @@ __device__ __forceinline__ void ln_affine_w(const f32x16 (&acc)[DT], f32x16 (&ev
 #pragma unroll
         for (int gg = 0; gg < 2; ++gg) {
             gm[K0 & 1][gg] = *(LdsVec4Ptr)(gp + 32 * (K0 >> 1) + 8 * (2 * (K0 & 1) + gg));
-            bt[K0 & 1][gg] = *(LdsVec4Ptr)(gp + D + 32 * (K0 >> 1) + 8 * (2 * (K0 & 1) + gg));
+            if constexpr (BETA) bt[K0 & 1][gg] = *(LdsVec4Ptr)(gp + D + 32 * (K0 >> 1) + 8 * (2 * (K0 & 1) + gg));
         }
         __builtin_amdgcn_sched_barrier(0);
         static_for_each([&](auto kc) __attribute__((always_inline)) {
@@ -296,7 +301,7 @@ __device__ __forceinline__ void ln_affine_w(const f32x16 (&acc)[DT], f32x16 (&ev
 #pragma unroll
                 for (int gg = 0; gg < 2; ++gg) {
                     gm[nxt][gg] = *(LdsVec4Ptr)(gp + 32 * t1 + 8 * (2 * s1 + gg));
-                    bt[nxt][gg] = *(LdsVec4Ptr)(gp + D + 32 * t1 + 8 * (2 * s1 + gg));
+                    if constexpr (BETA) bt[nxt][gg] = *(LdsVec4Ptr)(gp + D + 32 * t1 + 8 * (2 * s1 + gg));
                 }
             }
             if constexpr (w8dev::ABL_LN) {      // (timing-only: pack and add, keeps the MFMAs alive)
@@ -309,11 +314,17 @@ __device__ __forceinline__ void ln_affine_w(const f32x16 (&acc)[DT], f32x16 (&ev
                 // per value hipcc reuses ONE temporary and each fmac waits for the add right in front of it)
                 float nrm[8], bs[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) nrm[i] = __builtin_fmaf(acc[t][8 * s + i], st.rstd, st.nmr);
+                for (int i = 0; i < 8; ++i) nrm[i] = ZM ? acc[t][8 * s + i] * st.rstd : __builtin_fmaf(acc[t][8 * s + i], st.rstd, st.nmr);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (BETA) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) bs[i] = RES ? bt[cur][i >> 2][i & 3] + ev[t][8 * s + i] : bt[cur][i >> 2][i & 3];
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < 8; ++i) bs[i] = RES ? bt[cur][i >> 2][i & 3] + ev[t][8 * s + i] : bt[cur][i >> 2][i & 3];
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    static_assert(BETA || RES, "a pass without beta adds into the residual");
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) bs[i] = ev[t][8 * s + i];
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) ev[t][8 * s + i] = __builtin_fmaf(nrm[i], gm[cur][i >> 2][i & 3], bs[i]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -392,7 +403,7 @@ __device__ __forceinline__ void addp_rows(f32x16 (&acc)[DT], const bf16x8 (&ps)[
 //   last step    bias, MFMAs (first half of the next pass's sender rows and the receiver rows requested from their first
 //                slots), LayerNorm statistics, (waves 0-3: LayerNorm vectors -> side buffer)
 // Ring pieces go out in the first MFMA slots of every step; every step ends with RingW::interval_end.
-template <int DT, int NH, bool ENC, int LAG, bool PF16>
+template <int DT, int NH, bool ENC, int LAG, bool PF16, bool FOLD>
 __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
     S32Args a, const __bf16* __restrict__ ps_all, const __bf16* __restrict__ pd_all, int64_t round_stride,
     const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t num_edges, const float* e_in, float* e_out,
@@ -611,7 +622,7 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
                 }
                 // (measured and dropped: the selector MFMAs of a row tile right behind its two LayerNorm slices, so that they
                 // run under the next slices' vector work: no gain, four spilled registers)
-                ln_affine_w<PEND == 2, DT, KA, 2 * DT>(acc, ev, inb[0], ring.lnbuf(lnpar ^ 1), h, lnst);
+                ln_affine_w<PEND == 2, !(FOLD && PEND == 2), FOLD, DT, KA, 2 * DT>(acc, ev, inb[0], ring.lnbuf(lnpar ^ 1), h, lnst);
                 if constexpr (!IS_ENC) {
                     if constexpr (INBLK) read_pd_row(CGNN_IC(0)); else read_pd();
                 }
@@ -709,16 +720,17 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
                 if constexpr (WITH_P && q >= PQ && q < PQ + 4) stage_ps(CGNN_IC(0), CGNN_IC(q - PQ), nps);
                 if constexpr (WITH_P && q == PQ + 4) pdchunk = load_pd_chunk(npd, dchunk);
                 // LayerNorm's sums of a finished row tile, under the next row tile's MFMAs
-                if constexpr (t >= 0 && w == (KS > 4 ? CGNN_W8_SM0 : (KS > 2 ? 2 : KS - 1))) ln_sums_add<DT, (t < 0 ? 0 : t), 0>(sums, acc);
-                if constexpr (t >= 0 && w == (KS > 4 ? CGNN_W8_SM1 : KS - 1)) ln_sums_add<DT, (t < 0 ? 0 : t), 1>(sums, acc);
+                if constexpr (t >= 0 && w == (KS > 4 ? CGNN_W8_SM0 : (KS > 2 ? 2 : KS - 1))) ln_sums_add<FOLD, DT, (t < 0 ? 0 : t), 0>(sums, acc);
+                if constexpr (t >= 0 && w == (KS > 4 ? CGNN_W8_SM1 : KS - 1)) ln_sums_add<FOLD, DT, (t < 0 ? 0 : t), 1>(sums, acc);
             }));
             CGNN_W8_STAMP(2);
             // LayerNorm: the statistics and the first KA affine slices here (vectors straight from this chunk), the rest behind
             // the barrier
-            ln_sums_add<DT, DT - 1, 0>(sums, acc);
-            ln_sums_add<DT, DT - 1, 1>(sums, acc);
-            lnst = ln_stats_finish<DT>(sums);
-            ln_affine_w<RES, DT, 0, KA>(acc, ev, inb[0], ring.vec_addr() + (unsigned)D * 4u, h, lnst);
+            ln_sums_add<FOLD, DT, DT - 1, 0>(sums, acc);
+            ln_sums_add<FOLD, DT, DT - 1, 1>(sums, acc);
+            lnst = ln_stats_finish<FOLD, DT>(sums);
+            // FOLD: a round that has a successor (WITH_P) adds no beta (the caller folded it forward, include/cgnn.h)
+            ln_affine_w<RES, !(FOLD && RES && WITH_P), FOLD, DT, 0, KA>(acc, ev, inb[0], ring.vec_addr() + (unsigned)D * 4u, h, lnst);
             // the LayerNorm vectors of this chunk, for the affine part that runs in the next interval (when this slot may
             // already be refilled): waves 0-3 copy gamma | beta (2 D floats) aside
             if (wave < CGNN_W8_WAVES / 2) {
@@ -758,7 +770,7 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
             hidden_steps(ROUND_PASS);
         }
         step_last(ROUND_PASS, std::false_type{}, std::true_type{}, ps_all, pd_all);
-        ln_affine_w<true, DT, KA, 2 * DT>(acc, ev, inb[0], ring.lnbuf(lnpar ^ 1), h, lnst);
+        ln_affine_w<true, true, FOLD, DT, KA, 2 * DT>(acc, ev, inb[0], ring.lnbuf(lnpar ^ 1), h, lnst);
 
         if (valid) {
             // the final latents go past the caches (written once, not read again in this launch: as plain stores they
@@ -784,13 +796,13 @@ __global__ __launch_bounds__(CGNN_W8_BLOCK, 2) void edge_stream32w_kernel(
     __builtin_amdgcn_s_barrier();
 }
 
-template <int DT, int NH, int LAG, bool PF16>
+template <int DT, int NH, int LAG, bool PF16, bool FOLD>
 static int launch_w8(const S32Args& a, const __bf16* ps, const __bf16* pd, int64_t round_stride, const int32_t* src,
                      const int32_t* dst, int64_t num_edges, const float* e_in, float* e_out, const float* attr, int ld_attr,
                      int seg_k, hipStream_t st) {
     typedef W8Geom<DT> W;
     const bool enc = a.enc_in_dim > 0;
-    auto kern = enc ? edge_stream32w_kernel<DT, NH, true, LAG, PF16> : edge_stream32w_kernel<DT, NH, false, LAG, PF16>;
+    auto kern = enc ? edge_stream32w_kernel<DT, NH, true, LAG, PF16, FOLD> : edge_stream32w_kernel<DT, NH, false, LAG, PF16, FOLD>;
     if (W::LDS > 48 * 1024) {
         int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), W::LDS, "hipFuncSetAttribute(edge_stream32w)");
         if (rc != CGNN_OK) return rc;
@@ -836,7 +848,7 @@ extern "C" int cgnn_edge_stream_run_w8(const void* image, size_t image_bytes, in
                                        int32_t num_rounds, int32_t enc_in_dim, const void* ps_all, const void* pd_all,
                                        int64_t round_stride, const int32_t* src, const int32_t* dst, int64_t num_edges,
                                        const float* e_in, float* e_out, const float* edge_attr, int32_t ld_attr, int32_t lag,
-                                       int32_t fixed_k, int32_t p_format, void* stream) {
+                                       int32_t fixed_k, int32_t p_format, int32_t flags, void* stream) {
     if (!image || !ps_all || !pd_all || !src || !dst || !e_out || num_edges < 0 || num_rounds < 1 || num_hidden_layers < 1 ||
         round_stride < 0 || (enc_in_dim > 0 ? (!edge_attr || ld_attr < enc_in_dim) : !e_in) || lag < 0 || lag > 1 || fixed_k < 0) {
         set_error("cgnn_edge_stream_run_w8: invalid argument");
@@ -845,6 +857,10 @@ extern "C" int cgnn_edge_stream_run_w8(const void* image, size_t image_bytes, in
     if (p_format != CGNN_P_BF16_S32 && p_format != CGNN_P_F16_S32) {
         set_error("cgnn_edge_stream_run_w8: ps_all / pd_all must be CGNN_P_F16_S32 or CGNN_P_BF16_S32 tables (got p_format %d)",
                   p_format);
+        return CGNN_ERR_INVALID_ARG;
+    }
+    if ((flags & ~CGNN_STREAM_FOLDED) != 0 || ((flags & CGNN_STREAM_FOLDED) && p_format != CGNN_P_F16_S32)) {
+        set_error("cgnn_edge_stream_run_w8: flags = %d (known: CGNN_STREAM_FOLDED, with CGNN_P_F16_S32 tables only)", flags);
         return CGNN_ERR_INVALID_ARG;
     }
     if (p_format == CGNN_P_F16_S32 && lag != 0) {
@@ -875,27 +891,34 @@ extern "C" int cgnn_edge_stream_run_w8(const void* image, size_t image_bytes, in
     a.nh = num_hidden_layers;
     a.enc_in_dim = enc_in_dim > 0 ? enc_in_dim : 0;
     hipStream_t st = (hipStream_t)stream;
-#define CGNN_W8_GO(NHx, LAGx, PFx)                                                                                               \
-    return launch_w8<4, NHx, LAGx, PFx>(a, (const __bf16*)ps_all, (const __bf16*)pd_all, round_stride, src, dst, num_edges, e_in, \
-                                        e_out, edge_attr, ld_attr, fixed_k, st)
+#define CGNN_W8_GO(NHx, LAGx, PFx, FOLDx)                                                                                    \
+    return launch_w8<4, NHx, LAGx, PFx, FOLDx>(a, (const __bf16*)ps_all, (const __bf16*)pd_all, round_stride, src, dst, num_edges, \
+                                               e_in, e_out, edge_attr, ld_attr, fixed_k, st)
+    if (flags & CGNN_STREAM_FOLDED) {
+        switch (num_hidden_layers) {
+            case 1: CGNN_W8_GO(1, 0, true, true);
+            case 2: CGNN_W8_GO(2, 0, true, true);
+            default: CGNN_W8_GO(3, 0, true, true);
+        }
+    }
     if (p_format == CGNN_P_F16_S32) {
         switch (num_hidden_layers) {
-            case 1: CGNN_W8_GO(1, 0, true);
-            case 2: CGNN_W8_GO(2, 0, true);
-            default: CGNN_W8_GO(3, 0, true);
+            case 1: CGNN_W8_GO(1, 0, true, false);
+            case 2: CGNN_W8_GO(2, 0, true, false);
+            default: CGNN_W8_GO(3, 0, true, false);
         }
     }
     if (lag) {
         switch (num_hidden_layers) {
-            case 1: CGNN_W8_GO(1, 1, false);
-            case 2: CGNN_W8_GO(2, 1, false);
-            default: CGNN_W8_GO(3, 1, false);
+            case 1: CGNN_W8_GO(1, 1, false, false);
+            case 2: CGNN_W8_GO(2, 1, false, false);
+            default: CGNN_W8_GO(3, 1, false, false);
         }
     }
     switch (num_hidden_layers) {
-        case 1: CGNN_W8_GO(1, 0, false);
-        case 2: CGNN_W8_GO(2, 0, false);
-        default: CGNN_W8_GO(3, 0, false);
+        case 1: CGNN_W8_GO(1, 0, false, false);
+        case 2: CGNN_W8_GO(2, 0, false, false);
+        default: CGNN_W8_GO(3, 0, false, false);
     }
 #undef CGNN_W8_GO
 }

@@ -113,6 +113,55 @@ def _pack_mlp(module: nn.Module, precision, first_layer_cols=None) -> ops.Packed
                          first_layer_cols)
 
 
+def _centred_output(lin: nn.Module):
+    """(weight, bias) of an MLP's output Linear with the mean over its OUTPUT features removed: the LayerNorm that follows
+    (reference graph_network.py:38-42 ``build_mlp`` + ``LayerNorm``) sees ``y - mean(y)``, and ``LN(y) == LN(y - mean(y))``."""
+    w = lin.weight.detach().double()
+    w = (w - w.mean(dim=0, keepdim=True)).float()
+    b = lin.bias
+    if b is not None:
+        b = b.detach().double()
+        b = (b - b.mean()).float()
+    return w, b
+
+
+def _pack_mlp_centred(module: nn.Module, precision) -> ops.PackedMLP:
+    """``_pack_mlp`` of an MLP + LayerNorm with the output Linear centred (the same function of its input)."""
+    linears, ln = _split_mlp(module)
+    wb = [_wb(l) for l in linears[:-1]] + [_centred_output(linears[-1])]
+    return ops.PackedMLP(wb, (ln.weight, ln.bias), precision, None)
+
+
+def fold_edge_stream(edge_models: Sequence[nn.Module], latent: int):
+    """The rounds' edge models as ``CGNN_STREAM_FOLDED`` (include/cgnn.h) wants them: per round
+    ``(linears [(weight, bias)], (gamma, beta))`` -- the same function ``e_L`` of the inputs as the residual updates of
+    reference graph_network.py:89-90, :182, restated so that the one-launch kernel's LayerNorm needs neither a mean nor a shift:
+
+    * every output Linear is centred (``_centred_output``);
+    * with ``B_r = beta_0 + ... + beta_{r-1}`` the kernel carries ``e_r - B_r``: round r's first-Linear bias (which lives in
+      its Pd table) becomes ``b1_r + We_r B_r`` (``We_r``: the edge-latent block of the first Linear, ``cat`` order :89),
+      the LayerNorm shift of every round but the last becomes zero, the last round's becomes ``B_L`` (all of them at once).
+    """
+    D = latent
+    out = []
+    B = None
+    for r, mod in enumerate(edge_models):
+        linears, ln = _split_mlp(mod)
+        _materialize(linears[0], 3 * D)
+        w1, b1 = _wb(linears[0])
+        beta = ln.bias.detach().double()
+        if B is None:
+            B = torch.zeros_like(beta)
+        b1f = (b1.detach().double() if b1 is not None else torch.zeros(w1.shape[0], dtype=torch.float64, device=w1.device)) \
+            + w1.detach().double()[:, 2 * D:3 * D] @ B
+        last = r + 1 == len(edge_models)
+        B = B + beta
+        beta_img = B.float() if last else torch.zeros_like(ln.bias)
+        wb = [(w1, b1f.float())] + [_wb(l) for l in linears[1:-1]] + [_centred_output(linears[-1])]
+        out.append((wb, (ln.weight, beta_img)))
+    return out
+
+
 # ----------------------------------------------------------------------------
 # graph arrays the kernels want (int32, fixed in-degree detection)
 # ----------------------------------------------------------------------------
@@ -224,7 +273,10 @@ class _PackedProcessor:
     """Packed weights of one InteractionNetwork round."""
 
     def __init__(self, net: "InteractionNetwork", latent: int, edge_precision, node_precision,
-                 keep_32_row_edges: bool = False):
+                 keep_32_row_edges: bool = False, folded_edge=None):
+        """``folded_edge``: this round's entry of ``fold_edge_stream`` -- the edge model (and with it the Pd bias) is then
+        packed in that form: for the one-launch edge stream only (``keep_32_row_edges``), a folded round is not the
+        round-by-round kernels' round."""
         e_lin, e_ln = _split_mlp(net.edge_model)
         n_lin, n_ln = _split_mlp(net.node_model)
         if e_ln is None or n_ln is None:
@@ -234,6 +286,10 @@ class _PackedProcessor:
         _materialize(n_lin[0], 2 * D)
         w1e, b1e = _wb(e_lin[0])
         w1n, b1n = _wb(n_lin[0])
+        if folded_edge is not None:
+            if not keep_32_row_edges:
+                raise CgnnError("a folded edge model is the one-launch edge stream's (keep_32_row_edges)")
+            b1e = folded_edge[0][0][1]
         if w1e.shape[1] != 3 * D or w1n.shape[1] != 2 * D:
             raise CgnnError(f"first-layer fan-in {w1e.shape[1]}/{w1n.shape[1]} does not match latent size {D}")
         # cat([x[src], x[dest], edge_attr]) -> [Ws | Wd | We]      (reference graph_network.py:89)
@@ -251,7 +307,10 @@ class _PackedProcessor:
             proj_precision = edge_precision
         self.ws = ops.PackedLinear(w1e, None, proj_precision, 0, D)
         self.wd = ops.PackedLinear(w1e, b1e, proj_precision, D, D)
-        self.edge = _pack_mlp(net.edge_model, edge_precision, first_layer_cols=(2 * D, D))
+        if folded_edge is not None:
+            self.edge = ops.PackedMLP(folded_edge[0], folded_edge[1], edge_precision, (2 * D, D))
+        else:
+            self.edge = _pack_mlp(net.edge_model, edge_precision, first_layer_cols=(2 * D, D))
         # keep_32_row_edges: the model runs its edge stream through cgnn_edge_stream_run, which takes the 32-row packing
         wide = D == 256 and self.edge.hidden == 256 and self.edge.num_hidden_layers <= 3 and \
             all(l.bias is not None for l in _split_mlp(net.edge_model)[0])
@@ -355,7 +414,7 @@ def _run_rounds_fused(rounds, x: torch.Tensor, e, src, dst, fixed_k: int, agg: O
         x = ops.node_block(p.node, p.wx, p.wa, x, agg, x, True, nxt)
     if keep is not None:      # tests: what the one-launch edge stream is about to consume (EncodeProcessDecode.keep_stream_inputs)
         keep.update(ps_all=ps_all, pd_all=pd_all, src=src, dst=dst, edge_attr=edge_attr, p_format=fmt,
-                    e_in=None if e is None else e.to_rows())
+                    e_in=None if e is None else e.to_rows(), folded=bool(image is not None and image.folded))
     # `encoder` (the packed edge encoder) given: the initial edge latents are computed inside the same launch and
     # never written to memory (e is None then)
     if image is not None:      # cgnn_edge_stream_run: the rounds (and the encoder, if it is part of the image) as one image
@@ -491,17 +550,22 @@ class EncodeProcessDecode(nn.Module):
         if not tile32 and enc_edge.precision == _lib.BF16 and enc_edge.in_dim <= 32 and (wide_enc or (
                 D <= 128 and enc_edge.hidden <= 128 and enc_edge.lds_bytes() <= _lib.LDS_WEIGHT_BUDGET)):
             enc_edge = _pack_mlp(self.encoder.edge_model, "bf16_n16")    # 16-edge-per-wave encoder, TILED32 output
-        rounds = [_PackedProcessor(net, D, self.edge_precision, self.node_precision, keep_32_row_edges=tile32)
-                  for net in self.processor]
+        # the one-launch edge stream runs the rounds' edge models with their LayerNorms folded (CGNN_STREAM_FOLDED): the same
+        # e_L, 128 fewer vector instructions per 32-edge tile and round
+        folded = fold_edge_stream([net.edge_model for net in self.processor], D) if tile32 else None
+        rounds = [_PackedProcessor(net, D, self.edge_precision, self.node_precision, keep_32_row_edges=tile32,
+                                   folded_edge=folded[i] if folded is not None else None)
+                  for i, net in enumerate(self.processor)]
+        enc_image = _pack_mlp_centred(self.encoder.edge_model, self.edge_precision) if enc_in_image else None
         packed = dict(
             enc_node=_pack_mlp(self.encoder.node_model, self.node_precision),
             enc_edge=enc_edge,
             rounds=rounds,
             dec_acc=_pack_mlp(self.decoder_acc, self.node_precision),
             dec_tr=_pack_mlp(self.decoder_temp_rate, self.node_precision),
-            image=ops.StreamImage([p.edge for p in rounds], enc_edge if enc_in_image else None) if tile32 else None,
+            image=ops.StreamImage([p.edge for p in rounds], enc_image, folded=True) if tile32 else None,
             image_w8=None,      # the same for cgnn_edge_stream_run_w8 (every bias one chunk early), built on first use
-            image_parts=([p.edge for p in rounds], enc_edge if enc_in_image else None) if tile32 else None,
+            image_parts=([p.edge for p in rounds], enc_image) if tile32 else None,
         )
         self._packed = (key, packed)
         return packed
@@ -519,7 +583,7 @@ class EncodeProcessDecode(nn.Module):
         if not ok:
             return image, "tile32"
         if P["image_w8"] is None:
-            P["image_w8"] = ops.StreamImage(*P["image_parts"], kernel="tile32w")
+            P["image_w8"] = ops.StreamImage(*P["image_parts"], kernel="tile32w", folded=True)
         return P["image_w8"], "tile32w"
 
     def _can_fuse_rounds(self, rounds, latent: int) -> bool:

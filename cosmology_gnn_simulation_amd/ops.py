@@ -357,13 +357,17 @@ class StreamImage:
             return False
         return _lib.load().cgnn_edge_stream_image_bytes(latent, nh, rounds, 1 if enc_in is not None else 0) > 0
 
-    def __init__(self, mlps: Sequence[PackedMLP], encoder: Optional[PackedMLP] = None, kernel: str = "tile32"):
+    def __init__(self, mlps: Sequence[PackedMLP], encoder: Optional[PackedMLP] = None, kernel: str = "tile32",
+                 folded: bool = False):
         """``kernel``: which kernel the image is for -- ``"tile32w"`` (``cgnn_edge_stream_run_w8``) wants every bias one chunk
-        early (``cgnn_edge_stream_image_build_w8``); the images are not interchangeable."""
+        early (``cgnn_edge_stream_image_build_w8``); the images are not interchangeable.  ``folded``: the caller's promise
+        that ``mlps`` / ``encoder`` were packed from folded LayerNorms (``CGNN_STREAM_FOLDED``, include/cgnn.h;
+        ``graph_network.fold_edge_stream`` produces them): ``edge_stream_run`` then passes the flag to the kernels that use it."""
         lib = _lib.load()
         if kernel not in ("tile32", "tile32w"):
             raise CgnnError(f"StreamImage: unknown kernel {kernel!r}")
         self.kernel = kernel
+        self.folded = bool(folded)
         self.rounds = len(mlps)
         self.latent = mlps[0].out_dim
         self.nh = mlps[0].num_hidden_layers
@@ -392,7 +396,7 @@ def stream_w8_supported(latent: int, nh: int, fixed_k: int) -> bool:
 def edge_stream_run(image: StreamImage, ps_all: torch.Tensor, pd_all: torch.Tensor, src: torch.Tensor, dst: torch.Tensor,
                     e_in: Optional[TiledRows], e_out: Optional[TiledRows] = None,
                     edge_attr: Optional[torch.Tensor] = None, kernel: str = "tile32", lag: int = 1,
-                    fixed_k: int = 0) -> TiledRows:
+                    fixed_k: int = 0, folded: Optional[bool] = None) -> TiledRows:
     """All residual edge updates of ``image`` in one launch.  ``ps_all`` / ``pd_all``: ``[rounds, N, latent]`` bf16
     tables in ``CGNN_P_BF16_S32`` format -- or, ``"tile32w"`` with ``lag = 0`` only, float16 tables in ``CGNN_P_F16_S32``
     format (include/cgnn.h; the kernel then adds ``Ps[src] + Pd[dst]`` on the vector pipe instead of through selector
@@ -400,7 +404,8 @@ def edge_stream_run(image: StreamImage, ps_all: torch.Tensor, pd_all: torch.Tens
     ``edge_attr`` and ``e_in`` is ignored.  ``kernel``: ``"tile32"`` = ``cgnn_edge_stream_run`` (one wave per SIMD, two
     tiles per wave), ``"tile32w"`` = ``cgnn_edge_stream_run_w8`` (two waves per SIMD, one tile each; ``lag`` and
     ``fixed_k`` as in include/cgnn.h: the graph's fixed in-degree, ``dst[e] == e // fixed_k``; see
-    ``stream_w8_supported``)."""
+    ``stream_w8_supported``).  ``folded`` (default: what the image says): pass ``CGNN_STREAM_FOLDED`` where the kernel has
+    the shorter LayerNorm for it (``"tile32w"`` on float16 tables); every other kernel runs a folded image as a plain one."""
     if kernel not in ("tile32", "tile32w"):
         raise CgnnError(f"edge_stream_run: unknown kernel {kernel!r}")
     if image.kernel != kernel:
@@ -435,8 +440,10 @@ def edge_stream_run(image: StreamImage, ps_all: torch.Tensor, pd_all: torch.Tens
             edge_attr.stride(0) if edge_attr is not None else 0)
     with _timed("edge_stream", src.device):
         if kernel == "tile32w":
+            fold = image.folded if folded is None else bool(folded)
             check(_lib.load().cgnn_edge_stream_run_w8(*args, int(lag), int(fixed_k),
                                                       _lib.P_F16_S32 if pdt == torch.float16 else _lib.P_BF16_S32,
+                                                      _lib.STREAM_FOLDED if (fold and pdt == torch.float16) else 0,
                                                       stream_ptr(src.device)), "cgnn_edge_stream_run_w8")
         else:
             check(_lib.load().cgnn_edge_stream_run(*args, stream_ptr(src.device)), "cgnn_edge_stream_run")

@@ -281,7 +281,21 @@ int cgnn_edge_stream_run(const void* image, size_t image_bytes, int32_t latent, 
  * under the first layer's MFMAs; lag = 0 only) or CGNN_P_BF16_S32 (the tables of cgnn_edge_stream_run: the rows enter the
  * accumulators through four selector MFMAs per row tile, 14 % more matrix work per round).
  * Its image differs from cgnn_edge_stream_run's in one thing: every bias sits one chunk early (the kernel reads a layer's
- * bias while the previous layer still computes); cgnn_edge_stream_image_build_w8 builds it (same arguments and size). */
+ * bias while the previous layer still computes); cgnn_edge_stream_image_build_w8 builds it (same arguments and size).
+ * flags: CGNN_STREAM_FOLDED (CGNN_P_F16_S32 tables only) = the caller promises an image whose LayerNorms were folded:
+ *   (1) every pass's output Linear is CENTRED -- the mean over its output features was subtracted from each weight column
+ *       and from the bias (W[:, i] -= mean(W[:, i]), b -= mean(b): LayerNorm(y) == LayerNorm(y - mean(y)), so the model
+ *       is unchanged) -- its outputs then have zero mean up to the bf16 rounding of the centred weights (~2e-4 standard
+ *       deviations), and the kernel normalises with var = E[y^2] and no mean;
+ *   (2) the LayerNorm shift (beta) of every round that has a successor is zero in the image and was carried forward
+ *       instead: with B_r = beta_0 + ... + beta_{r-1} the residual stream the kernel holds is e_r - B_r, round r's Pd
+ *       table was projected with the bias b1_r + We_r B_r (We_r: the edge-latent block of round r's first Linear, as
+ *       rounded to bf16 in the image), and the LAST round's beta in the image is B_L = the sum of all rounds' betas
+ *       (the stored latents are e_L itself).  The encoder's LayerNorm keeps its beta.
+ * 128 fewer vector instructions per tile and round (LayerNorm: 64 adds of the mean's sum, 64 adds of beta); results
+ * differ from the unfolded kernel's by bf16 operand roundings of e_r - B_r instead of e_r (same error class).  Without
+ * the flag any image runs as before (a folded image is also a valid plain image: mean ~ 0 is computed, beta = 0 added). */
+#define CGNN_STREAM_FOLDED 1
 int cgnn_edge_stream_w8_supported(int32_t latent, int32_t num_hidden_layers, int32_t fixed_k);
 int cgnn_edge_stream_image_build_w8(const cgnn_mlp* rounds, int32_t num_rounds, const cgnn_mlp* encoder, int32_t latent,
                                     void* image, size_t image_bytes, void* stream);
@@ -289,7 +303,7 @@ int cgnn_edge_stream_run_w8(const void* image, size_t image_bytes, int32_t laten
                             int32_t num_rounds, int32_t enc_in_dim, const void* ps_all, const void* pd_all,
                             int64_t round_stride, const int32_t* src, const int32_t* dst, int64_t num_edges,
                             const float* e_in, float* e_out, const float* edge_attr, int32_t ld_attr, int32_t lag,
-                            int32_t fixed_k, int32_t p_format, void* stream);
+                            int32_t fixed_k, int32_t p_format, int32_t flags, void* stream);
 
 /* ---- backward of a row-wise MLP (+LayerNorm): the node stream of train.py:263 ------------------------
  * In reference-faithful mode only the node path carries gradient (the edge models' parameters get

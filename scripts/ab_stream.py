@@ -50,16 +50,17 @@ e = ops.TiledRows.from_rows(torch.randn(E, d, device=dev))
 flops = L * 6.0 * E * d * d + (0 if a.no_encoder else 2.0 * E * (32 * d + 2 * d * d))
 variants = []
 for v in a.variants.split(","):
-    kern, _, lag = v.partition(":")
-    variants.append((v, kern, int(lag or 0)))
+    kern, _, lag = v.partition(":")      # "tile32w:0f": timing of the CGNN_STREAM_FOLDED kernel (on an image that is not folded)
+    variants.append((v, kern, (int(lag.rstrip("f") or 0), lag.endswith("f"))))
 
 
-def run(kern, lag):
+def run(kern, lag_fold):
+    lag, fold = lag_fold
     ps_, pd_ = (ps16, pd16) if (kern == "tile32w" and (lag == 2 or (lag == 0 and not a.bf16_tables))) else (ps_all, pd_all)
     if a.no_encoder:
-        ops.edge_stream_run(images[kern], ps_, pd_, src, dst, e, e, None, kernel=kern, lag=lag, fixed_k=fk if a.fixed_k else 0)
+        ops.edge_stream_run(images[kern], ps_, pd_, src, dst, e, e, None, kernel=kern, lag=lag, fixed_k=fk if a.fixed_k else 0, folded=fold)
     else:
-        ops.edge_stream_run(images[kern], ps_, pd_, src, dst, None, e, ea, kernel=kern, lag=lag, fixed_k=fk if a.fixed_k else 0)
+        ops.edge_stream_run(images[kern], ps_, pd_, src, dst, None, e, ea, kernel=kern, lag=lag, fixed_k=fk if a.fixed_k else 0, folded=fold)
 
 
 times = {v[0]: [] for v in variants}

@@ -21,7 +21,7 @@ import torch
 
 # the bf16-operand arithmetic itself is part of the oracle (oracle/bf16_stream.py: reference citations, pinned against
 # cpu_ref on the CPU in every run); this file keeps the gates
-from oracle.bf16_stream import bf, dot_bf16, emulate_edge_stream_rows, s32_table_to_logical  # noqa: F401
+from oracle.bf16_stream import bf, dot_bf16, emulate_edge_stream_rows, fold_state_dict, s32_table_to_logical  # noqa: F401
 
 
 def row_rel_max(a: torch.Tensor, b: torch.Tensor, chunk: int = 1 << 20):

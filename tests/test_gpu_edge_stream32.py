@@ -44,14 +44,17 @@ def _rand_mlp(gen, fin, d, nh):
     return lin, ln
 
 
-def _emulate_mlp(lin, ln, first, ratios=None):
+def _emulate_mlp(lin, ln, first, ratios=None, no_mean=False):
     """first = pre-activation of layer 0 (bias included).  ``ratios``: a list that receives |mean| / std of every
-    LayerNorm input row (then LayerNorm itself runs centred, in float64: the yardstick for the kernels' one-pass variance)."""
+    LayerNorm input row (then LayerNorm itself runs centred, in float64: the yardstick for the kernels' one-pass variance).
+    ``no_mean``: y * rsqrt(E[y^2] + eps), the CGNN_STREAM_FOLDED kernel's LayerNorm of a centred output Linear."""
     h = bf(torch.relu(first))
     for w, b in lin[1:-1]:
         h = bf(torch.relu(_dot(h, w) + b))
     w, b = lin[-1]
     out = _dot(h, w) + b
+    if no_mean:
+        return out * torch.rsqrt((out * out).mean(1, keepdim=True) + 1e-5) * ln[0] + ln[1]
     if ratios is not None:
         ratios.append(out.mean(1).abs() / out.std(1, unbiased=False))
         return F.layer_norm(out.double(), (out.shape[1],), ln[0].double(), ln[1].double(), 1e-5).float()
@@ -72,25 +75,52 @@ def _problem(seed, n, k, d, nh, rounds, with_encoder, ragged=0):
     return src, dst, ps, pd, mlps, enc, attr, e0
 
 
-def _emulate(src, dst, ps, pd, mlps, enc, attr, e0, ratios=None):
+def _emulate(src, dst, ps, pd, mlps, enc, attr, e0, ratios=None, no_mean=False):
     s, t = src.long(), dst.long()
     if enc is not None:
         lin, ln = enc
-        e = _emulate_mlp(lin, ln, _dot(attr, lin[0][0]) + lin[0][1], ratios)
+        e = _emulate_mlp(lin, ln, _dot(attr, lin[0][0]) + lin[0][1], ratios, no_mean)
     else:
         e = e0.clone()
     for r, (lin, ln) in enumerate(mlps):
         first = (ps[r][s] + pd[r][t]) + _dot(e, lin[0][0])           # the round's layer-0 bias lives in Pd
-        e = e + _emulate_mlp(lin, ln, first, ratios)
+        e = e + _emulate_mlp(lin, ln, first, ratios, no_mean)
     return e
 
 
-# (kernel, lag[, "f16"]): see ops.edge_stream_run; "f16" = float16 (CGNN_P_F16_S32) tables, what the model feeds tile32w
-KERNELS = [("tile32", 0), ("tile32w", 0), ("tile32w", 1), ("tile32w", 0, "f16")]
+# (kernel, lag[, "f16"[, "fold"]]): see ops.edge_stream_run; "f16" = float16 (CGNN_P_F16_S32) tables; "fold" = the problem
+# with folded LayerNorms and the CGNN_STREAM_FOLDED flag (include/cgnn.h): what the model feeds tile32w
+KERNELS = [("tile32", 0), ("tile32w", 0), ("tile32w", 1), ("tile32w", 0, "f16"), ("tile32w", 0, "f16", "fold")]
 
 
 def _kid(kk):
-    return f"{kk[0]}-lag{kk[1]}" + ("-f16" if len(kk) > 2 else "")
+    return f"{kk[0]}-lag{kk[1]}" + ("-f16" if len(kk) > 2 else "") + ("-fold" if len(kk) > 3 else "")
+
+
+def _centre(lin):
+    w, b = lin[-1]
+    w, b = w.double(), b.double()
+    return lin[:-1] + [((w - w.mean(0, keepdim=True)).float(), (b - b.mean()).float())]
+
+
+def _fold(prob):
+    """The problem with its LayerNorms folded (include/cgnn.h, CGNN_STREAM_FOLDED; restated here on the test's own tensors):
+    output Linears centred, B_r = beta_0 + .. + beta_{r-1} carried into round r's Pd values (We_r B_r: the bias the caller's
+    projection would add), no shift in any round but the last, which takes B_L.  The same e_L in exact arithmetic."""
+    src, dst, ps, pd, mlps, enc, attr, e0 = prob
+    d = ps.shape[-1]
+    B = torch.zeros(d, dtype=torch.float64, device=ps.device)
+    pd2, out = pd.clone(), []
+    for r, (lin, ln) in enumerate(mlps):
+        pd2[r] = pd[r] + (lin[0][0].double() @ B).float()
+        B = B + ln[1].double()
+        out.append((_centre(lin), (ln[0], B.float() if r + 1 == len(mlps) else torch.zeros_like(ln[1]))))
+    return (src, dst, ps, pd2, out, None if enc is None else (_centre(enc[0]), enc[1]), attr, e0)
+
+
+def _as_fed(prob, kernel):
+    """What _run hands the kernel, and what the emulation therefore starts from: the folded problem for a "fold" kernel."""
+    return _fold(prob) if len(kernel) > 3 else prob
 
 
 def _p_as_the_kernel_sees_it(prob, kernel):
@@ -114,9 +144,11 @@ def _fixed_k(prob, n, k):
 
 
 def _run(src, dst, ps, pd, mlps, enc, attr, e0, kernel=("tile32", 0), fixed_k=0):
+    if len(kernel) > 3:
+        src, dst, ps, pd, mlps, enc, attr, e0 = _fold((src, dst, ps, pd, mlps, enc, attr, e0))
     packed = [ops.PackedMLP([(lin[0][0], None)] + lin[1:], ln, "bf16") for lin, ln in mlps]
     penc = ops.PackedMLP(enc[0], enc[1], "bf16") if enc is not None else None
-    image = ops.StreamImage(packed, penc, kernel=kernel[0])
+    image = ops.StreamImage(packed, penc, kernel=kernel[0], folded=len(kernel) > 3)
     e_in = None if enc is not None else ops.TiledRows.from_rows(e0)
     pdt = torch.float16 if len(kernel) > 2 else torch.bfloat16
     out = ops.edge_stream_run(image, _s32_table(ps, pdt), _s32_table(pd, pdt), src, dst, e_in, None,
@@ -156,7 +188,7 @@ def test_edge_stream_run_matches_bf16_emulation(n, k, d, nh, rounds, with_enc, r
     if kernel[0] == "tile32w":
         prob, fixed_k = _fixed_k(prob, n, k), k
     got = _run(*prob, kernel=kernel, fixed_k=fixed_k)
-    want = _emulate(*_p_as_the_kernel_sees_it(prob, kernel))
+    want = _emulate(*_p_as_the_kernel_sees_it(_as_fed(prob, kernel), kernel), no_mean=len(kernel) > 3)
     assert got.shape == want.shape
     scale = float(want.abs().max())
     err = (got - want).abs()
@@ -164,6 +196,9 @@ def test_edge_stream_run_matches_bf16_emulation(n, k, d, nh, rounds, with_enc, r
     assert float((got - want).norm() / want.norm()) <= 1e-3
     # every tile was written: no row left at its initial value / garbage
     assert torch.isfinite(got).all()
+    if len(kernel) > 3:      # the folded problem is the same model: bf16-rounding distance from the plain problem's emulation
+        plain = _emulate(*_p_as_the_kernel_sees_it(prob, kernel))
+        assert float((want - plain).norm() / plain.norm()) <= 1e-2
 
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=_kid)
@@ -186,6 +221,8 @@ def test_edge_stream_layernorm_rows_with_a_large_mean(kernel, offset, min_ratio,
     if kernel[0] == "tile32w":
         prob, fixed_k = _fixed_k(prob, n, k), k
     ratios = []
+    # (a "fold" kernel never sees these means: centring the output Linear removes the constant with them.  Its yardstick
+    # is the same plain emulation; what it differs by is the bf16 rounding of e_r - B_r instead of e_r)
     want = _emulate(*_p_as_the_kernel_sees_it(prob, kernel), ratios=ratios)
     med = float(torch.cat(ratios).median())
     assert med >= min_ratio, med
@@ -204,8 +241,9 @@ def test_edge_stream_run_is_deterministic_and_in_place(kernel):
     b = _run(*prob, kernel=kernel, fixed_k=fk)
     assert torch.equal(a, b)
     src, dst, ps, pd, mlps, enc, attr, e0 = prob
+    src, dst, ps, pd, mlps, enc, attr, e0 = _as_fed(prob, kernel)
     packed = [ops.PackedMLP([(lin[0][0], None)] + lin[1:], ln, "bf16") for lin, ln in mlps]
-    image = ops.StreamImage(packed, None, kernel=kernel[0])
+    image = ops.StreamImage(packed, None, kernel=kernel[0], folded=len(kernel) > 3)
     e = ops.TiledRows.from_rows(e0)
     pdt = torch.float16 if len(kernel) > 2 else torch.bfloat16
     ops.edge_stream_run(image, _s32_table(ps, pdt), _s32_table(pd, pdt), src, dst, e, e, kernel=kernel[0], lag=kernel[1], fixed_k=fk)   # e_out aliases e_in
@@ -230,6 +268,11 @@ def test_two_waves_per_simd_kernel_on_every_supported_in_degree(k):
         f16 = _run(*prob, kernel=("tile32w", 0, "f16"), fixed_k=k)
         assert float((f16 - _emulate(*_p_as_the_kernel_sees_it(prob, ("tile32w", 0, "f16")))).abs().max()) <= 1e-2 * float(want.abs().max())
         assert float((f16 - got).norm() / got.norm()) <= 1e-3
+        # ... and with folded LayerNorms (the same model restated: bf16-rounding distance from the plain kernels)
+        fk = ("tile32w", 0, "f16", "fold")
+        fold = _run(*prob, kernel=fk, fixed_k=k)
+        assert float((fold - _emulate(*_p_as_the_kernel_sees_it(_fold(prob), fk), no_mean=True)).abs().max()) <= 1e-2 * float(want.abs().max())
+        assert float((fold - got).norm() / got.norm()) <= 1e-2
     with pytest.raises(ops.CgnnError):       # not a supported in-degree: the caller must take cgnn_edge_stream_run
         _run(*_fixed_k(_problem(3, 100, 12, 128, 2, 2, False), 100, 12), kernel=("tile32w", 1), fixed_k=12)
     assert not ops.stream_w8_supported(128, 2, 0) and not ops.stream_w8_supported(64, 2, 16)
@@ -270,3 +313,29 @@ def test_edge_stream_image_rejects_what_it_cannot_hold():
     lin2, ln2 = _rand_mlp(gen, 64, 64, 1)
     with pytest.raises(ops.CgnnError):       # rounds of different depth
         ops.StreamImage([good, ops.PackedMLP([(lin2[0][0], None)] + lin2[1:], ln2, "bf16")], None)
+
+
+def test_two_waves_per_simd_kernel_rejects_flags_it_does_not_know():
+    """CGNN_STREAM_FOLDED is a promise about the image AND the Pd tables: it is accepted with fp16 tables only (the kernel
+    that uses it), unknown bits are refused (include/cgnn.h)."""
+    from cosmology_gnn_simulation_amd import _lib
+    from cosmology_gnn_simulation_amd.ops import stream_ptr
+    n, k, d = 64, 16, 128
+    src, dst, ps, pd, mlps, enc, attr, e0 = _fixed_k(_problem(9, n, k, d, 2, 2, False), n, k)
+    packed = [ops.PackedMLP([(lin[0][0], None)] + lin[1:], ln, "bf16") for lin, ln in mlps]
+    image = ops.StreamImage(packed, None, kernel="tile32w")
+    e = ops.TiledRows.from_rows(e0)
+    lib = _lib.load()
+
+    def call(tables_dtype, p_format, flags):
+        tps, tpd = _s32_table(ps, tables_dtype), _s32_table(pd, tables_dtype)
+        rc = lib.cgnn_edge_stream_run_w8(image.buf.data_ptr(), image.buf.numel(), d, 2, 2, 0, tps.data_ptr(), tpd.data_ptr(),
+                                         tps.stride(0), src.data_ptr(), dst.data_ptr(), n * k, e.buf.data_ptr(), e.buf.data_ptr(),
+                                         None, 0, 0, k, p_format, flags, stream_ptr(src.device))
+        torch.cuda.synchronize()
+        return rc
+    assert call(torch.float16, _lib.P_F16_S32, 0) == 0
+    assert call(torch.float16, _lib.P_F16_S32, _lib.STREAM_FOLDED) == 0
+    assert call(torch.bfloat16, _lib.P_BF16_S32, _lib.STREAM_FOLDED) != 0
+    assert call(torch.float16, _lib.P_F16_S32, 2) != 0
+    assert b"flags" in lib.cgnn_last_error()

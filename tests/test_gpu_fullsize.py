@@ -198,7 +198,10 @@ def test_cfg3_forward_as_benched_at_full_size(cfg3_graph):
     ne = es.shape[0]
     rows = ec.sample_rows(ne, 4096, seed=3)
     assert rows.numel() >= 4096
-    want_rows = ec.emulate_edge_stream_rows(sd, rows, si, d, 2, L, with_encoder=True)
+    # the model hands the one-launch kernel its edge models with folded LayerNorms (CGNN_STREAM_FOLDED: the same e_L,
+    # oracle/bf16_stream.fold_state_dict, pinned on CPU in tests/test_oracle_bf16_stream.py); the Pd tables carry the fold's bias
+    assert si["folded"]
+    want_rows = ec.emulate_edge_stream_rows(ec.fold_state_dict(sd, d, 2, L), rows, si, d, 2, L, with_encoder=True, folded=True)
     ec.assert_rows_match_emulation(es[rows], want_rows, rows)
     bad_tile = int(rows[rows.numel() // 2]) // 32
     with ec.corrupted_tile(es, bad_tile):

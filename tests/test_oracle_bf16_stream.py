@@ -72,3 +72,36 @@ def test_row_subset_form_equals_the_all_edges_form():
         rows = torch.arange(0, ei.shape[1], 7)
         got = bf16_stream.emulate_edge_stream_rows(sd, rows, stream_inputs, latent, nh, steps)
     assert torch.equal(got, want[rows])
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_k16_box25", "cfg1"])
+def test_folded_parameters_are_the_same_model(name):
+    """fold_state_dict (CGNN_STREAM_FOLDED, include/cgnn.h: centred output Linears, LayerNorm shifts carried forward into the
+    next round's first-Linear bias) leaves the final edge latents AND the node outputs of the f32 oracle unchanged -- the
+    intermediate edge latents differ by B_r -- and the bf16 restatement of the folded model stays within the same bound."""
+    g = load_golden(name)
+    sd, nh, steps, latent = g["state_dict"], int(g["nh"]), int(g["steps"]), int(g["latent"])
+    x, ea = torch.from_numpy(g["x"]), torch.from_numpy(g["edge_attr"])
+    ei = edge_index_from(g)
+    fsd = bf16_stream.fold_state_dict(sd, latent, nh, steps)
+    changed = {k for k in sd if not torch.equal(sd[k], fsd[k])}
+    assert changed and all(".edge_model." in k for k in changed), changed
+    with torch.no_grad():
+        ref = cpu_ref.encode_process_decode(sd, x, ei, ea, nh, steps, return_latents=True)
+        fold = cpu_ref.encode_process_decode(fsd, x, ei, ea, nh, steps, return_latents=True)
+        assert rel_l2(fold["edge_latent"], ref["edge_latent"]) <= 2e-6
+        assert torch.equal(fold["acceleration"], ref["acceleration"]) and torch.equal(fold["x_latent"], ref["x_latent"])
+        # the folded model's LayerNorm inputs have no mean, and only its last round shifts
+        xs, _ = _node_latents_per_round(sd, x, ei, ea, nh, steps)
+        e_bf = bf16_stream.emulate_from_node_latents(fsd, xs, ei, ea, latent, nh, torch.float16, folded=True)
+        # LayerNorm without a mean on centred weights: the plain LayerNorm up to what bf16 leaves of the mean (~1e-4 sigma),
+        # amplified by the operand-rounding flips of the following rounds
+        e_ln = bf16_stream.emulate_from_node_latents(fsd, xs, ei, ea, latent, nh, torch.float16)
+        assert rel_l2(e_bf, e_ln) <= 5e-3
+    for r in range(steps):
+        w = fsd[f"processor.{r}.edge_model.0.{2 * nh}.weight"]
+        assert float(w.sum(dim=0).abs().max()) <= 1e-5 * float(w.abs().max()) * w.shape[0]
+        beta = fsd[f"processor.{r}.edge_model.1.bias"]
+        assert (r + 1 == steps) or not beta.any()
+    err = rel_l2(e_bf, ref["edge_latent"])
+    assert 1e-4 <= err <= 3e-2, err
