@@ -187,6 +187,16 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
         F2R_BARRIER();
         F2R_STAMP(9);
         char* const stage = cgnn_smem + RING_OFF + (slot == 0 ? NS - 1 : slot - 1) * CHUNK + wave * 2048;
+        // Staging layout: row R of the tile at R * 128, its 16-byte piece j at slot j ^ ((R >> 1) & 7).  Unswizzled, the
+        // sixteen lanes of a write pass (one piece of sixteen rows: addresses 128 bytes apart) met in two bank groups of
+        // four -- an 8-way conflict on every staging write: SQ_LDS_BANK_CONFLICT 8.8e7 cycles per launch, a quarter of
+        // the kernel's time on the port that bounds it (round 4: 8.0e6 left, the 8-byte P writes at 2-way; -9.5 %).
+        // Rotated by the row PAIR (even rows start at bank 0, odd rows at bank 32) they cover all 64 banks, and a read
+        // pass (two whole rows) still does.
+        const unsigned sw_w = (unsigned)((c >> 1) & 7);                       // writer: row c
+        const unsigned sw_r = (unsigned)((lane >> 4) & 7);                    // reader: rows lane >> 3 and (lane >> 3) + 8
+        char* const stage_rd0 = stage + (lane >> 3) * 128 + (((unsigned)(lane & 7) ^ sw_r) << 4);
+        char* const stage_rd1 = stage + ((lane >> 3) + 8) * 128 + (((unsigned)(lane & 7) ^ sw_r ^ 4u) << 4);
         const int64_t tile_row = (step * WAVES + wave) * 16;
         const bool ok0 = tile_row + (lane >> 3) < a.n, ok1 = tile_row + (lane >> 3) + 8 < a.n;    // rows of the staged stores
         fold16f2<OT>(c0, c1);
@@ -200,11 +210,9 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
                     c0[2 * p] += xv[2 * p];
                     c0[2 * p + 1] += xv[2 * p + 1];
                 }
-                const LdsF4Ptr w = (LdsF4Ptr)(stage + c * 128 + q * 16);
-                w[0] = c0[2 * p];
-                w[4] = c0[2 * p + 1];
-                const LdsF4Ptr r = (LdsF4Ptr)(stage + lane * 16);
-                const f32x4 v0 = r[0], v1 = r[64];
+                *(LdsF4Ptr)(stage + c * 128 + (((unsigned)q ^ sw_w) << 4)) = c0[2 * p];
+                *(LdsF4Ptr)(stage + c * 128 + (((unsigned)q ^ sw_w ^ 4u) << 4)) = c0[2 * p + 1];
+                const f32x4 v0 = *(LdsF4Ptr)stage_rd0, v1 = *(LdsF4Ptr)stage_rd1;
                 if (ok0) *reinterpret_cast<f32x4*>(xo + p * 32) = v0;
                 if (ok1) *reinterpret_cast<f32x4*>(xo + p * 32 + 8 * D) = v1;
             }
@@ -224,7 +232,9 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
                 for (int pp = 0; pp < OT / 4; ++pp) {
 #pragma unroll
                     for (int oo = 0; oo < 4; ++oo) {
-                        char* const sp = stage + c * 128 + (q & 1) * 64 + (4 * (oo >> 1) + 2 * (oo & 1) + (q >> 1)) * 8;
+                        // byte (q & 1) * 64 + (4 (oo >> 1) + 2 (oo & 1) + (q >> 1)) * 8 of the row: 8-byte half q >> 1 of piece
+                        // 4 (q & 1) + 2 (oo >> 1) + (oo & 1)
+                        char* const sp = stage + c * 128 + (((unsigned)(4 * (q & 1) + 2 * (oo >> 1) + (oo & 1)) ^ sw_w) << 4) + (q >> 1) * 8;
                         if constexpr (PFMT == CGNN_P_F16_S32) {      // the same order, fp16 values
                             typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
                             f16x4v v;
@@ -238,8 +248,7 @@ __global__ __launch_bounds__(CGNN_F2R_BLOCK) void node_block_f2ring_kernel(F2Rin
                             *(LdsB4Ptr)sp = v;
                         }
                     }
-                    const LdsU4Ptr r = (LdsU4Ptr)(stage + lane * 16);
-                    const u32x4 v0 = r[0], v1 = r[64];
+                    const u32x4 v0 = *(LdsU4Ptr)stage_rd0, v1 = *(LdsU4Ptr)stage_rd1;
                     if (ok0) *reinterpret_cast<u32x4*>(pt + pp * PP_STRIDE) = v0;
                     if (ok1) *reinterpret_cast<u32x4*>(pt + pp * PP_STRIDE + 8 * D * 2) = v1;
                 }
