@@ -105,3 +105,28 @@ def test_folded_parameters_are_the_same_model(name):
         assert (r + 1 == steps) or not beta.any()
     err = rel_l2(e_bf, ref["edge_latent"])
     assert 1e-4 <= err <= 3e-2, err
+
+
+@pytest.mark.parametrize("name", ["tiny", "cfg1"])
+def test_the_engines_fold_is_the_oracles_fold(name):
+    """graph_network.fold_edge_stream (what the model packs for CGNN_STREAM_FOLDED) and oracle fold_state_dict (the yardstick's
+    restatement of it) are written independently and must produce the same parameters, bit for bit: the GPU gates compare
+    the kernel on the first with the emulation on the second."""
+    from cosmology_gnn_simulation_amd import graph_network
+    g = load_golden(name)
+    sd, nh, steps, latent = g["state_dict"], int(g["nh"]), int(g["steps"]), int(g["latent"])
+    hidden = sd["processor.0.edge_model.0.0.weight"].shape[0]
+    out_dim = sd[f"decoder_acc.{2 * nh}.weight"].shape[0]
+    m = graph_network.EncodeProcessDecode(latent, hidden, nh, steps, out_dim)
+    m._materialize_all(int(g["x"].shape[1]), int(g["edge_attr"].shape[1]))
+    m.load_state_dict(sd)
+    folded = graph_network.fold_edge_stream([net.edge_model for net in m.processor], latent)
+    fsd = bf16_stream.fold_state_dict(sd, latent, nh, steps)
+    for r, (wb, (gamma, beta)) in enumerate(folded):
+        pre = f"processor.{r}.edge_model"
+        for i, (w, b) in enumerate(wb):
+            assert torch.equal(w.detach(), fsd[f"{pre}.0.{2 * i}.weight"]), (r, i)
+            assert torch.equal(b.detach(), fsd[f"{pre}.0.{2 * i}.bias"]), (r, i)
+        assert torch.equal(gamma.detach(), fsd[f"{pre}.1.weight"]) and torch.equal(beta.detach(), fsd[f"{pre}.1.bias"]), r
+    w, b = graph_network._centred_output(graph_network._split_mlp(m.encoder.edge_model)[0][-1])
+    assert torch.equal(w, fsd[f"encoder.edge_model.0.{2 * nh}.weight"]) and torch.equal(b, fsd[f"encoder.edge_model.0.{2 * nh}.bias"])
