@@ -378,6 +378,24 @@ class ShardedForward:
         ops.node_block(p.node, p.wx, p.wa, x_own, self.agg, x_own, True, nxt)
         self._projected = nxt is not None
 
+    def _interior_launch_rows(self) -> int:
+        """Rows of the "interior" launches: ``n_interior`` rounded DOWN to whole grid waves of the node kernel.  A launch of
+        s 128-row steps on c workgroups (one per CU) takes ceil(s / c) step times, so the remainder of the interior rows cost
+        a whole extra step time there -- 849 steps on 256 CUs: four step times for 3.3 of work at 125 k rows per rank -- and
+        nothing in the boundary launch, which is far from full; rows that need no ghost may run after the exchange just as well."""
+        ni = self.sh.n_interior
+        cached = self.__dict__.get("_ni_launch")
+        if cached is not None and cached[0] == ni:
+            return cached[1]
+        dev = self.sh.x_feat.device
+        rows = ni
+        if dev.type == "cuda":
+            wave_rows = 128 * torch.cuda.get_device_properties(dev).multi_processor_count
+            if ni >= wave_rows:
+                rows = ni - ni % wave_rows
+        self._ni_launch = (ni, rows)
+        return rows
+
     def _src_part(self, a: int, b: int) -> torch.Tensor:
         """The sender list of owned receivers [a, b) as one tensor OBJECT per part (the aggregation plan is cached on it)."""
         parts = self.__dict__.setdefault("_src_parts", {})
@@ -394,7 +412,7 @@ class ShardedForward:
         sh = self.sh
         rounds = self.P["rounds"]
         p = rounds[i]
-        no, ni, k = sh.n_owned, sh.n_interior, sh.k
+        no, ni, k = sh.n_owned, self._interior_launch_rows(), sh.k
         a, b = {"all": (0, no), "interior": (0, ni), "boundary": (ni, no)}[part]
         if part != "interior" and sh.n_ghost:
             ops.project_nodes(p.ws, None, self.x_all[no:], self.ps[i][no:], None, self.p_fmt)
